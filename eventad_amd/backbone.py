@@ -1,0 +1,202 @@
+"""Native (HIP) execution of the frozen DAGR backbone -- the product path behind
+`dagr.model.networks.net.Net.forward` (reference src/dagr/model/networks/net.py:106-197).
+
+Host logic only: weight preparation (LUT / concatenated kernel matrices / folded BatchNorm),
+workspace ownership (torch tensors = device memory plumbing) and the sequence of C-ABI calls.
+No host<->device synchronisation happens inside `forward`; node and edge counts of the pooled
+graphs stay on the device (`n_dev`), so the whole forward is hipGraph-capturable."""
+import torch
+
+from . import _lib, spline
+from ._lib import call, ptr
+from .geometry import Geometry
+from .weights import LAYER_NAMES, LAYER_DIMS
+
+FEATURE_CHANNELS = [16, 64, 64, 64, 64]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Level:
+    """Node/edge arrays of one pooled graph level (padded to n_max; valid count in n_dev)."""
+    pass
+
+
+class NativeBackbone:
+    def __init__(self, state_dict, width, height, device, radius=0.01, max_neighbors=16,
+                 pooling_dim_at_output="5x7", time_window=1000000, prefix="backbone."):
+        _lib.load()
+        self.geom = Geometry(width, height, radius, max_neighbors, pooling_dim_at_output, time_window)
+        self.device = torch.device(device)
+        self.prefix = prefix
+        self._ws_key = None
+        self.load_weights(state_dict)
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, sd):
+        g, dev, pre = self.geom, self.device, self.prefix
+        sd = {k: v.detach().float().cpu() for k, v in sd.items() if k.startswith(pre)}
+        w = {}
+        # event-level Layer (conv_block1): LUT per spiral step, Cin padded 19 -> 20
+        p1, p2 = pre + "conv_block1.conv_block1.", pre + "conv_block1.conv_block2."
+        w["lut1"] = spline.lut_by_spiral_step(sd[p1 + "conv.weight"], g, 20)
+        w["root1"] = spline.pad_rows(sd[p1 + "conv.lin.weight"].t().contiguous(), 20)
+        w["bn1"] = spline.fold_bn(sd, p1 + "norm.module.")
+        w["lut2"] = spline.lut_by_spiral_step(sd[p2 + "conv.weight"], g, 16)
+        w["root2"] = sd[p2 + "conv.lin.weight"].t().contiguous()
+        w["bn2"] = spline.fold_bn(sd, p2 + "norm.module.")
+        w["wskip"] = spline.pad_rows(sd[p2 + "lin.mlp.weight"].t().contiguous(), 20)
+        w["bns"] = spline.fold_bn(sd, p2 + "norm_skip.module.")
+        # pooled Layers: X.[W_0..W_24 | root | skip]  and  Y1.[W_0..W_24 | root]
+        self.tail = []
+        for name, (cin, cout) in list(zip(LAYER_NAMES, LAYER_DIMS))[1:]:
+            q1, q2 = "%s%s.conv_block1." % (pre, name), "%s%s.conv_block2." % (pre, name)
+            cin_pad = (cin + 3) // 4 * 4
+            wc1 = torch.cat([sd[q1 + "conv.weight"].permute(1, 0, 2).reshape(cin, 25 * cout),
+                             sd[q1 + "conv.lin.weight"].t(), sd[q2 + "lin.mlp.weight"].t()], dim=1)
+            wc2 = torch.cat([sd[q2 + "conv.weight"].permute(1, 0, 2).reshape(cout, 25 * cout),
+                             sd[q2 + "conv.lin.weight"].t()], dim=1)
+            t = dict(cin=cin, cin_pad=cin_pad, wc1=spline.pad_rows(wc1, cin_pad).to(dev), wc2=wc2.contiguous().to(dev),
+                     bn1=[v.to(dev) for v in spline.fold_bn(sd, q1 + "norm.module.")],
+                     bn2=[v.to(dev) for v in spline.fold_bn(sd, q2 + "norm.module.")],
+                     bns=[v.to(dev) for v in spline.fold_bn(sd, q2 + "norm_skip.module.")])
+            self.tail.append(t)
+        self.w = {k: ([t.to(dev) for t in v] if isinstance(v, tuple) else v.to(dev)) for k, v in w.items()}
+
+    # ---------------------------------------------------------------- workspace
+    def _alloc(self, N, B):
+        if self._ws_key == (N, B):
+            return self.ws
+        g, dev = self.geom, self.device
+        P = B * g.H * g.W
+        K = g.max_neighbors
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        ws = dict(
+            counters=torch.zeros(4, dtype=torch.int32, device=dev),
+            key=i32(N), tq=i32(N), bev=i32(N), pix_count=i32(P + 1), pix_start=i32(P + 1),
+            scan_tmp=i32(max(P, 1 << 16) // 2048 + 4), sid_tmp=i32(N), sid=i32(N), long_list=i32(P),
+            key_s=i32(N), ts_s=i32(N), posn_s=f32(N, 3), x0s=f32(N, 20),
+            ell_src=i32(N, K), ell_step=torch.empty((N, K), dtype=torch.int16, device=dev), deg=i32(N),
+            y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N),
+        )
+        levels = []
+        for lv in range(4):
+            nx, ny = g.grid[lv]
+            S = nx * ny * (B + 1)
+            C = 80 if lv == 0 else 128
+            ldx = C + 4                                      # [features | pos_x | pos_y | 0 0]
+            L = Level()
+            L.nx, L.ny, L.S, L.C, L.ldx, L.n_max = nx, ny, S, C, ldx, S
+            L.feat = i32(S, C); L.sums = torch.empty((S, 2), dtype=torch.int64, device=dev)
+            L.tsum = f32(S); L.cnt = i32(S); L.maxidx = i32(S)
+            L.occ = i32(S + 1); L.slot2node = i32(S); L.bitmap = i32(S, 3)
+            L.x = f32(S, ldx); L.npos = f32(S, 3); L.npix = i32(S, 2); L.nbatch = i32(S); L.node_slot = i32(S)
+            L.n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            L.e_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            L.rowptr = i32(S + 2); L.csr_src = i32(S * 75); L.csr_dxy = i32(S * 75)
+            L.z1 = f32(S, 27 * 64); L.z2 = f32(S, 26 * 64); L.y1 = f32(S, 64); L.y = f32(S, 64)
+            L.node_slot_in = i32(S)                          # slot of each of this level's nodes in the NEXT pooling
+            levels.append(L)
+        ws["levels"] = levels
+        self.ws, self._ws_key = ws, (N, B)
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, pos, polarity, batch, num_graphs, image_feats, feats_are_nhwc=False):
+        """pos f32[N,3] normalised (format_data output), polarity f32[N] or [N,1], batch i64[N],
+        image_feats: the five CNN feature maps ([B,C,h,w], or [B,h,w,C] if feats_are_nhwc).
+        Returns a dict with out3/out4 node arrays (padded) and their device-side counts."""
+        g, st = self.geom, _stream()
+        N, B = int(pos.shape[0]), int(num_graphs)
+        ws = self._alloc(N, B)
+        pos = pos.contiguous().float()
+        polarity = polarity.reshape(-1).contiguous().float()
+        batch = batch.contiguous().long()
+        maps = []
+        for m in image_feats:
+            m = m.contiguous().float()
+            if feats_are_nhwc:
+                maps.append(m)
+            else:
+                o = torch.empty((m.shape[0], m.shape[2], m.shape[3], m.shape[1]), dtype=torch.float32, device=m.device)
+                call("eventad_nchw_to_nhwc", ptr(m), ptr(o), m.shape[0], m.shape[1], m.shape[2], m.shape[3], st)
+                maps.append(o)
+        assert [m.shape[3] for m in maps] == FEATURE_CHANNELS and all(m.shape[0] == B for m in maps)
+        ws["counters"].zero_()
+        w, K = self.w, g.max_neighbors
+        call("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
+             N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
+             ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["long_list"]), ptr(ws["counters"]),
+             ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), st)
+        call("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
+             N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), st)
+        call("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
+             ptr(w["root1"]), ptr(w["bn1"][0]), ptr(w["bn1"][1]), ptr(ws["y1"]), N, g.steps, K, st)
+        call("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
+             ptr(w["lut2"]), ptr(w["root2"]), ptr(w["bn2"][0]), ptr(w["bn2"][1]), ptr(w["wskip"]), ptr(w["bns"][0]),
+             ptr(w["bns"][1]), ptr(ws["y2"]), N, g.steps, K, st)
+        levels = ws["levels"]
+        out3 = None
+        for lv in range(4):
+            L = levels[lv]
+            vsx, vsy = g.voxel[lv]
+            mean = 1 if g.pool_aggr[lv] == "mean" else 0
+            fmap = maps[lv + 1]
+            if lv == 0:
+                call("eventad_pool_scatter", ptr(ws["y2"]), 16, 16, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
+                     ptr(ws["posn_s"]), None, None, ptr(ws["key_s"]), ptr(ws["sid"]), N, None, g.W, g.H, vsx, vsy,
+                     L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
+                     ptr(ws["node_slot0"]), ptr(ws["counters"]), st)
+                boi = ws["bev"]
+            else:
+                Lp = levels[lv - 1]
+                call("eventad_pool_scatter", ptr(Lp.y), 64, 64, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
+                     ptr(Lp.npos), ptr(Lp.npix), ptr(Lp.nbatch), None, None, Lp.n_max, ptr(Lp.n_dev), g.W, g.H, vsx, vsy,
+                     L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
+                     ptr(Lp.node_slot_in), ptr(ws["counters"]), st)
+                boi = Lp.nbatch
+            call("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(boi),
+                 L.nx, L.ny, B, L.C, mean, 1 if lv == 0 else 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
+                 ptr(ws["scan_tmp"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
+                 ptr(L.slot2node), ptr(L.n_dev), st)
+            if lv == 0:
+                call("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
+                     L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
+            else:
+                Lp = levels[lv - 1]
+                call("eventad_pool_edges_mark_csr", ptr(Lp.rowptr), ptr(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
+                     ptr(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
+            call("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
+                 ptr(L.n_dev), L.nx, L.ny, ptr(L.rowptr), ptr(ws["scan_tmp"]), ptr(L.csr_src), ptr(L.csr_dxy),
+                 ptr(L.e_dev), st)
+            # Layer lv+2 on this level's graph
+            t = self.tail[lv]
+            dvx, dvy = g.lut_div[lv + 1]
+            call("eventad_gemm_f32", ptr(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, ptr(L.n_dev),
+                 27 * 64, t["cin_pad"], None, None, None, None, 0, 0, st)
+            call("eventad_tail_blend", ptr(L.z1), 27 * 64, 25, None, 0, 0, ptr(L.rowptr), ptr(L.csr_src), ptr(L.csr_dxy),
+                 L.n_max, ptr(L.n_dev), dvx, dvy, ptr(t["bn1"][0]), ptr(t["bn1"][1]), None, None, ptr(L.y1), 64, st)
+            call("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, ptr(L.n_dev),
+                 26 * 64, 64, None, None, None, None, 0, 0, st)
+            call("eventad_tail_blend", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, ptr(L.rowptr), ptr(L.csr_src),
+                 ptr(L.csr_dxy), L.n_max, ptr(L.n_dev), dvx, dvy, ptr(t["bn2"][0]), ptr(t["bn2"][1]), ptr(t["bns"][0]),
+                 ptr(t["bns"][1]), ptr(L.y), 64, st)
+            if lv == 2:
+                out3 = dict(x=L.y, pos=L.npos, batch=L.nbatch, n_dev=L.n_dev, level=L)
+        L = levels[3]
+        out4 = dict(x=L.y, pos=L.npos, batch=L.nbatch, n_dev=L.n_dev, level=L)
+        return dict(out3=out3, out4=out4, ws=ws, flags=ws["counters"])
+
+    def check_flags(self):
+        """Lazy, synchronising check of the data-dependent error flags (fails loudly)."""
+        f = int(self.ws["counters"][0].item())
+        if f & 2:
+            raise RuntimeError("eventad_amd: an event lies outside the sensor / batch range")
+        if f & 4:
+            raise RuntimeError("eventad_amd: pooled edge outside the 5x5x3 voxel window (unsupported geometry)")
+        if f & 8:
+            raise RuntimeError("eventad_amd: normalised event time outside [0,1]")
+        return f

@@ -1,0 +1,452 @@
+// eventad_amd/csrc/graph.hip -- spatio-temporal radius-graph construction for gfx950.
+//
+// Two families of entry points (declared in include/eventad_hip.h):
+//
+//  (A) reference-compatible: eventad_insert_in_queue / _single / eventad_fill_edges operate on the
+//      reference's own dense FIFO tensor `queue` i32[B,Q,H,W] and int64 edge buffer, so they are a
+//      drop-in for the pybind module `ev_graph_cuda` (reference src/dagr/graph/ev_graph.cu:82-128,
+//      215-276).  Same results bit for bit; launched on the caller's stream.
+//
+//  (B) native: eventad_sort_events + eventad_build_ell.  No dense FIFO (268 MB..3.8 GB of -1 fill
+//      per batch in the reference): events are counting-sorted by pixel (CSR over pixels), which
+//      *is* the FIFO content -- the FIFO of a pixel after one batch insert holds its newest Q
+//      events newest-first (ev_graph.cu:201-211), i.e. the tail of the pixel's id-sorted segment.
+//      The edge search (ev_graph.cu:15-80) then walks the same spiral over CSR segments and writes
+//      an ELL adjacency (<=16 sources per destination, self edge first) in PIXEL-SORTED node
+//      numbering, so the layer-1 neighbour gathers that follow hit nearby rows.
+#include "common.h"
+
+// ------------------------------------------------------------------ spiral (reference spiral.h)
+// Offsets are generated on the host once per radius (eventad_spiral_offsets) and passed as a table.
+extern "C" int eventad_spiral_offsets(int radius, int16_t* dxdy /* [(2r+1)^2][2] host memory */) {
+    if (radius < 0 || !dxdy) return EVAD_ERR_ARG;
+    int steps = (2 * radius + 1) * (2 * radius + 1);
+    int x = 0, y = 0, layer = 1, leg = 0;
+    for (int i = 0; i < steps; ++i) {
+        dxdy[2 * i] = (int16_t)x; dxdy[2 * i + 1] = (int16_t)y;
+        if (leg == 0)      { ++x; if (x == layer) ++leg; }
+        else if (leg == 1) { ++y; if (y == layer) ++leg; }
+        else if (leg == 2) { --x; if (-x == layer) ++leg; }
+        else               { --y; if (-y == layer) { leg = 0; ++layer; } }
+    }
+    return steps;
+}
+
+// =============================================================================================
+// (A) reference-compatible kernels
+// =============================================================================================
+__global__ void k_insert_in_queue(const int32_t* __restrict__ indices, const int32_t* __restrict__ unique_coords,
+                                  const int32_t* __restrict__ cumsum, int32_t* __restrict__ queue,
+                                  int Q, int H, int W, int K) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    int offset = k > 0 ? cumsum[k - 1] : 0;
+    int counts = cumsum[k] - offset;
+    int c = unique_coords[k];
+    int x = c % W, y = ((c - x) / W) % H, b = c / (W * H);
+    int64_t plane = (int64_t)H * W;
+    int32_t* col = queue + (int64_t)b * plane * Q + (int64_t)y * W + x;   // FIFO column of this pixel
+    // shift the old content down by `counts`, newest new ids go to slots 0..counts-1
+    for (int q = Q - 1; q >= 0; --q)
+        col[q * plane] = (q >= counts) ? col[(q - counts) * plane] : indices[offset + counts - 1 - q];
+}
+
+__global__ void k_insert_in_queue_single(const int32_t* __restrict__ indices, const int32_t* __restrict__ events,
+                                         int32_t* __restrict__ queue, int Q, int H, int W) {
+    if (blockIdx.x * blockDim.x + threadIdx.x != 0) return;
+    int x = events[0], y = events[1];
+    int64_t plane = (int64_t)H * W;
+    int32_t* col = queue + (int64_t)y * W + x;                              // clip index forced to 0
+    for (int q = Q - 1; q >= 1; --q) col[q * plane] = col[(q - 1) * plane];
+    col[0] = indices[0];
+}
+
+__global__ void k_fill_edges(const int32_t* __restrict__ batch, const int32_t* __restrict__ pos,
+                             const int32_t* __restrict__ all_ts, const int32_t* __restrict__ indices,
+                             const int32_t* __restrict__ queue, const int16_t* __restrict__ spiral,
+                             int64_t* __restrict__ edges, int Q, int H, int W, int N, int64_t K,
+                             int steps, float delta_t_us, int max_nb, int min_index) {
+    int ev = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ev >= N) return;
+    int b = batch[ev], x = pos[3 * ev], y = pos[3 * ev + 1], ts = pos[3 * ev + 2];
+    int me = indices[ev];
+    int64_t off = (int64_t)ev * max_nb;
+    int nn = 0;
+    edges[off] = me - min_index;  edges[off + K] = me - min_index;  nn = 1;       // self edge
+    int64_t plane = (int64_t)H * W;
+    for (int i = 0; i < steps && nn < max_nb; ++i) {
+        int xn = x + spiral[2 * i], yn = y + spiral[2 * i + 1];
+        if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
+        const int32_t* col = queue + (int64_t)b * plane * Q + (int64_t)yn * W + xn;
+        for (int q = 0; q < Q; ++q) {
+            int idx = col[q * plane];
+            if (idx < min_index) break;                                   // FIFO exhausted
+            if (me > idx) {
+                int dt = ts - all_ts[idx - min_index];
+                if ((float)dt > delta_t_us) continue;                     // too old: keeps scanning
+                edges[off + nn] = idx - min_index;  edges[off + nn + K] = me - min_index;
+                if (++nn >= max_nb) break;
+            }
+        }
+    }
+}
+
+static int16_t* g_spiral_dev = nullptr;     // small cached device copy of the spiral table
+static int g_spiral_radius = -1;
+
+static int ensure_spiral(int radius, hipStream_t st, int* steps_out) {
+    int steps = (2 * radius + 1) * (2 * radius + 1);
+    if (radius != g_spiral_radius) {
+        int16_t* host = (int16_t*)malloc(sizeof(int16_t) * 2 * steps);
+        eventad_spiral_offsets(radius, host);
+        if (g_spiral_dev) hipFree(g_spiral_dev);
+        if (hipMalloc(&g_spiral_dev, sizeof(int16_t) * 2 * steps) != hipSuccess) { free(host); return -2; }
+        hipMemcpyAsync(g_spiral_dev, host, sizeof(int16_t) * 2 * steps, hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);
+        free(host);
+        g_spiral_radius = radius;
+    }
+    *steps_out = steps;
+    return 0;
+}
+
+extern "C" int eventad_insert_in_queue(const int32_t* indices, const int32_t* unique_coords,
+                                       const int32_t* cumsum_counts, int32_t* queue,
+                                       int B, int Q, int H, int W, int K, void* stream) {
+    if (!indices || !unique_coords || !cumsum_counts || !queue || B <= 0 || Q <= 0 || H <= 0 || W <= 0 || K < 0)
+        return EVAD_ERR_ARG;
+    if (K == 0) return EVAD_OK;
+    hipLaunchKernelGGL(k_insert_in_queue, dim3(evad_blocks(K, 256)), dim3(256), 0, (hipStream_t)stream,
+                       indices, unique_coords, cumsum_counts, queue, Q, H, W, K);
+    return evad_last_error();
+}
+
+extern "C" int eventad_insert_in_queue_single(const int32_t* indices, const int32_t* events, int32_t* queue,
+                                              int B, int Q, int H, int W, void* stream) {
+    if (!indices || !events || !queue || B <= 0 || Q <= 0 || H <= 0 || W <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_insert_in_queue_single, dim3(1), dim3(64), 0, (hipStream_t)stream, indices, events, queue, Q, H, W);
+    return evad_last_error();
+}
+
+extern "C" int eventad_fill_edges(const int32_t* batch, const int32_t* pos, const int32_t* all_timestamps,
+                                  const int32_t* event_queue, const int32_t* indices, int max_num_neighbors,
+                                  float radius, float delta_t_us, int64_t* edges, int min_index,
+                                  int B, int Q, int H, int W, int N, int64_t K, void* stream) {
+    if (!batch || !pos || !all_timestamps || !event_queue || !indices || !edges || max_num_neighbors < 1 ||
+        radius < 0 || B <= 0 || Q <= 0 || H <= 0 || W <= 0 || N < 0 || K < (int64_t)N * max_num_neighbors)
+        return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    int steps;
+    if (ensure_spiral((int)radius, (hipStream_t)stream, &steps)) return -2;
+    hipLaunchKernelGGL(k_fill_edges, dim3(evad_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       batch, pos, all_timestamps, indices, event_queue, g_spiral_dev, edges, Q, H, W, N, K,
+                       steps, delta_t_us, max_num_neighbors, min_index);
+    return evad_last_error();
+}
+
+// =============================================================================================
+// generic exclusive scan (u32), used for pixel CSR, voxel compaction and pooled-edge row pointers
+// =============================================================================================
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* total) {
+    __shared__ unsigned wave_sums[SCAN_THREADS / 64];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_sums[wv] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) { if (w < wv) base += wave_sums[w]; tot += wave_sums[w]; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const unsigned* __restrict__ in, unsigned* __restrict__ out,
+                                                             unsigned* __restrict__ tile_sums, long long n) {
+    long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    unsigned v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; s += v[k]; }
+    unsigned tot, ex = block_exclusive_scan(s, &tot);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(unsigned* __restrict__ tile_sums, int n_tiles,
+                                                            unsigned* __restrict__ grand_total) {
+    unsigned carry = 0;
+    for (int base = 0; base < n_tiles; base += SCAN_THREADS) {
+        int i = base + threadIdx.x;
+        unsigned v = i < n_tiles ? tile_sums[i] : 0u, tot;
+        unsigned ex = block_exclusive_scan(v, &tot);
+        if (i < n_tiles) tile_sums[i] = ex + carry;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+
+__global__ void k_scan_add(unsigned* __restrict__ out, const unsigned* __restrict__ tile_sums, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += tile_sums[i / SCAN_TILE];
+}
+
+// out has n+1 entries (out[n] = grand total); tile_sums needs ceil(n/2048) entries.  in may alias out.
+int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, hipStream_t st) {
+    if (n <= 0) { hipMemsetAsync(out, 0, sizeof(unsigned), st); return evad_last_error(); }
+    int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(SCAN_THREADS), 0, st, in, out, tile_sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, tiles, out + n);
+    if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(evad_blocks(n, 256)), dim3(256), 0, st, out, tile_sums, n);
+    return evad_last_error();
+}
+
+extern "C" int eventad_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, int64_t n, void* stream) {
+    if (!in || !out || !tile_sums || n < 0) return EVAD_ERR_ARG;
+    return evad_exclusive_scan(in, out, tile_sums, n, (hipStream_t)stream);
+}
+
+// =============================================================================================
+// (B) native path: counting sort by pixel + ELL edge search
+// =============================================================================================
+// denormalize_pos (reference ev_tgn.py:11-16): (int)(W*pos + 1e-3) with separate fp32 mul and add.
+__device__ __forceinline__ int denorm(float p, float scale) { return (int)__fadd_rn(__fmul_rn(scale, p), 1e-3f); }
+
+__global__ void k_prep_events(const float* __restrict__ pos, const long long* __restrict__ batch, int N, int B, int W,
+                              int H, int T, int* __restrict__ key, int* __restrict__ tq, int* __restrict__ bev,
+                              unsigned* __restrict__ count, unsigned* __restrict__ flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float pt = pos[3 * i + 2];
+    int x = denorm(pos[3 * i], (float)W), y = denorm(pos[3 * i + 1], (float)H), t = denorm(pt, (float)T);
+    int b = (int)batch[i];
+    unsigned f = 0;
+    if (x < 0 || x >= W || y < 0 || y >= H || b < 0 || b >= B) {
+        f |= EVAD_FLAG_POS_OUT_OF_FOV;
+        x = min(max(x, 0), W - 1); y = min(max(y, 0), H - 1); b = min(max(b, 0), B - 1);
+    }
+    if (!(pt >= 0.f && pt <= 1.f)) f |= EVAD_FLAG_T_OUT_OF_RANGE;
+    if (i > 0 && (int)batch[i - 1] == b && denorm(pos[3 * i - 1], (float)T) > t) f |= EVAD_FLAG_T_NOT_MONOTONE;
+    if (f) atomicOr(flags, f);
+    int k = x + W * (y + H * b);
+    key[i] = k; tq[i] = t; bev[i] = b;
+    atomicAdd(&count[k], 1u);
+}
+
+__global__ void k_scatter_events(const int* __restrict__ key, const unsigned* __restrict__ start,
+                                 unsigned* __restrict__ count, int* __restrict__ sid_tmp, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int k = key[i];
+    unsigned c = atomicSub(&count[k], 1u);               // old value: 1..cnt
+    sid_tmp[start[k] + c - 1] = i;
+}
+
+// Order every pixel segment by event id (rank placement; ids are unique).  Short segments are
+// done by one thread; long ones are queued for the wave-cooperative kernel below.
+#define SEG_SHORT 32
+__global__ void k_order_short(const unsigned* __restrict__ start, const int* __restrict__ sid_tmp, int* __restrict__ sid,
+                              int P, int* __restrict__ long_list, unsigned* __restrict__ long_count) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    unsigned st = start[p], en = start[p + 1];
+    unsigned len = en - st;
+    if (len == 0) return;
+    if (len == 1) { sid[st] = sid_tmp[st]; return; }
+    if (len > SEG_SHORT) { long_list[atomicAdd(long_count, 1u)] = p; return; }
+    for (unsigned a = 0; a < len; ++a) {
+        int v = sid_tmp[st + a]; unsigned rank = 0;
+        for (unsigned c = 0; c < len; ++c) rank += (sid_tmp[st + c] < v);
+        sid[st + rank] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_order_long(const unsigned* __restrict__ start, const int* __restrict__ sid_tmp,
+                                                    int* __restrict__ sid, const int* __restrict__ long_list,
+                                                    const unsigned* __restrict__ long_count) {
+    int lane = threadIdx.x & 63;
+    unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned n_long = *long_count;
+    for (unsigned w = wave; w < n_long; w += n_waves) {
+        int p = long_list[w];
+        unsigned st = start[p], len = start[p + 1] - st;
+        for (unsigned a = lane; a < len; a += 64) {
+            int v = sid_tmp[st + a]; unsigned rank = 0;
+            for (unsigned c = 0; c < len; ++c) rank += (sid_tmp[st + c] < v);
+            sid[st + rank] = v;
+        }
+    }
+}
+
+// Sorted-order event records + the 19(+1)-channel layer-1 input row
+//   x0s[r] = [polarity, 16 bilinear samples of CNN map 0, pos_x, pos_y, 0]   (reference net.py:116,122-123)
+// The sampler restates F.grid_sample(align_corners=True, zeros padding) as called by
+// net.py:211-228; the batch coordinate is integral so the trilinear blend reduces to bilinear.
+__device__ __forceinline__ void bilinear_setup(float px_norm, float py_norm, float Wf, float Hf, int w_in, int h_in,
+                                               int* x0, int* y0, float* fx, float* fy) {
+    float x = __fmul_rn(px_norm, Wf), y = __fmul_rn(py_norm, Hf);
+    float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, x), Wf - 1.f), 1.f);
+    float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, y), Hf - 1.f), 1.f);
+    float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.f), 2.f), (float)(w_in - 1));
+    float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yn, 1.f), 2.f), (float)(h_in - 1));
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    *x0 = (int)fx0; *y0 = (int)fy0; *fx = ix - fx0; *fy = iy - fy0;
+}
+
+__global__ void k_gather_sorted(const int* __restrict__ sid, const int* __restrict__ key, const int* __restrict__ tq,
+                                const float* __restrict__ pos, const float* __restrict__ pol,
+                                const float* __restrict__ map0 /* NHWC [B,h,w,16] */, int h_in, int w_in,
+                                int N, int W, int H, int* __restrict__ key_s, int* __restrict__ ts_s,
+                                float* __restrict__ posn_s, float* __restrict__ x0s) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    int i = sid[r];
+    int k = key[i];
+    key_s[r] = k; ts_s[r] = tq[i];
+    float px = pos[3 * i], py = pos[3 * i + 1], pt = pos[3 * i + 2];
+    posn_s[3 * r] = px; posn_s[3 * r + 1] = py; posn_s[3 * r + 2] = pt;
+    int b = k / (W * H);
+    int x0, y0; float fx, fy;
+    bilinear_setup(px, py, (float)W, (float)H, w_in, h_in, &x0, &y0, &fx, &fy);
+    float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    bool vx0 = x0 >= 0 && x0 < w_in, vx1 = x0 + 1 >= 0 && x0 + 1 < w_in;
+    bool vy0 = y0 >= 0 && y0 < h_in, vy1 = y0 + 1 >= 0 && y0 + 1 < h_in;
+    const float4* m = (const float4*)(map0 + (size_t)b * h_in * w_in * 16);
+    float4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](bool ok, int yy, int xx, float w) {
+        if (!ok) return;
+        const float4* p = m + ((size_t)yy * w_in + xx) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 v = p[c];
+            acc[c].x += v.x * w; acc[c].y += v.y * w; acc[c].z += v.z * w; acc[c].w += v.w * w;
+        }
+    };
+    add(vx0 && vy0, y0, x0, w00); add(vx1 && vy0, y0, x0 + 1, w01);
+    add(vx0 && vy1, y0 + 1, x0, w10); add(vx1 && vy1, y0 + 1, x0 + 1, w11);
+    float4* o = (float4*)(x0s + (size_t)r * 20);
+    o[0] = make_float4(pol[i], acc[0].x, acc[0].y, acc[0].z);
+    o[1] = make_float4(acc[0].w, acc[1].x, acc[1].y, acc[1].z);
+    o[2] = make_float4(acc[1].w, acc[2].x, acc[2].y, acc[2].z);
+    o[3] = make_float4(acc[2].w, acc[3].x, acc[3].y, acc[3].z);
+    o[4] = make_float4(acc[3].w, px, py, 0.f);
+}
+
+extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const float* polarity,
+                                   const float* map0_nhwc, int map_h, int map_w,
+                                   int N, int B, int W, int H, int T,
+                                   int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
+                                   uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid, int32_t* long_list,
+                                   uint32_t* counters /* [0]=flags [1]=long_count */,
+                                   int32_t* key_s, int32_t* ts_s, float* posn_s, float* x0s, void* stream) {
+    if (!pos || !batch || !polarity || !map0_nhwc || !key || !tq || !bev || !pix_count || !pix_start || !scan_tmp ||
+        !sid_tmp || !sid || !long_list || !counters || !key_s || !ts_s || !posn_s || !x0s ||
+        N < 0 || B <= 0 || W <= 0 || H <= 0 || T <= 0 || map_h <= 0 || map_w <= 0)
+        return EVAD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    long long P = (long long)B * H * W;
+    if (P >= (1ll << 31)) return EVAD_ERR_ARG;
+    hipMemsetAsync(pix_count, 0, sizeof(uint32_t) * (P + 1), st);
+    hipMemsetAsync(counters + 1, 0, sizeof(uint32_t), st);
+    if (N > 0)
+        hipLaunchKernelGGL(k_prep_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, pos, (const long long*)batch, N, B,
+                           W, H, T, key, tq, bev, pix_count, counters);
+    int rc = evad_exclusive_scan(pix_count, pix_start, scan_tmp, P, st);
+    if (rc) return rc;
+    if (N == 0) return evad_last_error();
+    hipLaunchKernelGGL(k_scatter_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, pix_count, sid_tmp, N);
+    hipLaunchKernelGGL(k_order_short, dim3(evad_blocks(P, 256)), dim3(256), 0, st, pix_start, sid_tmp, sid, (int)P,
+                       long_list, counters + 1);
+    hipLaunchKernelGGL(k_order_long, dim3(512), dim3(256), 0, st, pix_start, sid_tmp, sid, long_list, counters + 1);
+    hipLaunchKernelGGL(k_gather_sorted, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid, key, tq, pos, polarity,
+                       map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, posn_s, x0s);
+    return evad_last_error();
+}
+
+// Edge search over pixel CSR segments (semantics of ev_graph.cu:15-80, see header comment).
+// One thread per destination event, in pixel-sorted order r.  Writes ELL row r:
+//   ell_src[r][k] = sorted position of the k-th source (k=0 is the self edge),
+//   ell_step[r][k] = spiral step (= LUT cell) of that source's pixel,  deg[r] = number of slots used.
+__global__ __launch_bounds__(256) void k_build_ell(const int* __restrict__ sid, const int* __restrict__ ts_s,
+                                                   const int* __restrict__ key_s, const unsigned* __restrict__ start,
+                                                   const int16_t* __restrict__ spiral, const unsigned* __restrict__ flags,
+                                                   int N, int W, int H, int steps, int Q, int dt_max, int max_nb,
+                                                   int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
+                                                   int* __restrict__ deg) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const bool monotone = !(*flags & EVAD_FLAG_T_NOT_MONOTONE);
+    int k = key_s[r], me = sid[r], ts = ts_s[r];
+    int x = k % W, y = (k / W) % H;
+    int plane_base = k - x - W * y;                     // W*H*b
+    int* row = ell_src + (size_t)r * max_nb;
+    uint16_t* srow = ell_step + (size_t)r * max_nb;
+    row[0] = r; srow[0] = 0;
+    int nn = 1;
+    for (int i = 0; i < steps && nn < max_nb; ++i) {
+        int xn = x + spiral[2 * i], yn = y + spiral[2 * i + 1];
+        if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
+        int p = plane_base + xn + W * yn;
+        int st = (int)start[p], en = (int)start[p + 1];
+        int lo = max(st, en - Q);                        // the FIFO keeps only the newest Q ids
+        for (int s = en - 1; s >= lo; --s) {
+            if (me > sid[s]) {
+                // dt > delta: the reference keeps scanning (`continue`); with timestamps that are
+                // non-decreasing in id every older entry fails too, so the scan can stop.
+                if ((float)(ts - ts_s[s]) > (float)dt_max) { if (monotone) break; else continue; }
+                row[nn] = s; srow[nn] = (uint16_t)i;
+                if (++nn >= max_nb) break;
+            }
+        }
+    }
+    deg[r] = nn;
+}
+
+extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* key_s, const uint32_t* pix_start,
+                                 const uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
+                                 int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
+                                 int32_t* deg, void* stream) {
+    if (!sid || !ts_s || !key_s || !pix_start || !counters || !ell_src || !ell_step || !deg || N < 0 || B <= 0 ||
+        W <= 0 || H <= 0 || radius_px < 0 || max_num_neighbors < 1 || max_num_neighbors > 65535 || queue_size < 1)
+        return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    int steps;
+    if (ensure_spiral(radius_px, (hipStream_t)stream, &steps)) return -2;
+    if (steps > 65535) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_build_ell, dim3(evad_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, sid, ts_s, key_s,
+                       pix_start, g_spiral_dev, counters, N, W, H, steps, queue_size, delta_t_us, max_num_neighbors,
+                       ell_src, ell_step, deg);
+    return evad_last_error();
+}
+
+// ELL (sorted numbering) -> the reference's edge_index layout, event numbering: int64[2][16N]
+// prefilled with -1, slot [i*16+k] (reference ev_graph.cu:44-45,71-72).  Used by parity tests and
+// by callers that want `edge_index` itself.
+__global__ void k_ell_to_edges(const int* __restrict__ ell_src, const int* __restrict__ deg, const int* __restrict__ sid,
+                               int N, int max_nb, long long K, long long* __restrict__ edges) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * max_nb) return;
+    int r = (int)(t / max_nb), k = (int)(t % max_nb);
+    int i = sid[r];
+    long long o = (long long)i * max_nb + k;
+    if (k < deg[r]) { edges[o] = sid[ell_src[t]]; edges[o + K] = i; }
+    else            { edges[o] = -1;              edges[o + K] = -1; }
+}
+
+extern "C" int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32_t* sid, int N,
+                                    int max_num_neighbors, int64_t K, int64_t* edges, void* stream) {
+    if (!ell_src || !deg || !sid || !edges || N < 0 || K < (int64_t)N * max_num_neighbors) return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    hipLaunchKernelGGL(k_ell_to_edges, dim3(evad_blocks((long long)N * max_num_neighbors, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ell_src, deg, sid, N, max_num_neighbors, (long long)K, (long long*)edges);
+    return evad_last_error();
+}

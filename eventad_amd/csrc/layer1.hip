@@ -1,0 +1,132 @@
+// eventad_amd/csrc/layer1.hip -- the two event-level spline convolutions of DAGR's first Layer.
+//
+// Reference: Layer/ConvBlock/ConvBlockWithSkip (src/dagr/model/layers/conv.py:10-72) around
+// MySplineConv with the cached LUT message (src/dagr/model/layers/spline_conv.py:39-78):
+//     out_i = sum_{j->i} LUT[dx_ji, dy_ji]^T x_j  +  W_root x_i ;  y = ReLU(BN(out))            (conv 1)
+//     y2    = ReLU( BN(out2) + BN_skip(W_skip x_i) )                                            (conv 2)
+// The reference gathers LUT[dx,dy] into an [E,Cin,Cout] temporary (36.6 GB in its own comment,
+// spline_conv.py:43-44) and scatter-adds.  Here every destination owns <=16 contiguous ELL slots
+// (graph.hip), the LUT (one Cin x 16 matrix per spiral step, 49 steps at r=3) lives in LDS, and
+// 4 lanes per destination each keep 4 output channels in registers: no atomics, no temporary.
+// Messages are added in ELL slot order (self edge, then spiral order) = the reference's edge order.
+#include "common.h"
+
+template <int CINP>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[CINP]) {
+#pragma unroll
+    for (int q = 0; q < CINP / 4; ++q) {
+        float4 v = ((const float4*)p)[q];
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+}
+
+template <int CINP>
+__device__ __forceinline__ float4 matvec4(const float (&x)[CINP], const float* __restrict__ w /* [CINP][16] at lane offset */) {
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < CINP; ++k) {
+        float4 wv = *(const float4*)(w + k * 16);
+        m.x = fmaf(x[k], wv.x, m.x); m.y = fmaf(x[k], wv.y, m.y);
+        m.z = fmaf(x[k], wv.z, m.z); m.w = fmaf(x[k], wv.w, m.w);
+    }
+    return m;
+}
+
+// LUT row stride in LDS: CINP*16 floats + 16 pad so consecutive steps start 16 banks apart
+// (ds_read_b128 banks are (addr/4)%64; an unpadded CINP*16 stride is a multiple of 64 for CINP=20,16).
+template <int CINP, bool SKIP, bool LUT_IN_LDS>
+__global__ __launch_bounds__(256) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
+                                                 const uint16_t* __restrict__ ell_step, const int* __restrict__ deg,
+                                                 const float* __restrict__ lut, const float* __restrict__ root,
+                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                 const float* __restrict__ xskip, const float* __restrict__ wskip,
+                                                 const float* __restrict__ sscale, const float* __restrict__ sshift,
+                                                 float* __restrict__ out, int N, int steps, int max_nb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LS = CINP * 16 + 16;
+    float* s_root = smem;                                 // [CINP][16]
+    float* s_skip = s_root + CINP * 16;                   // [20][16] (SKIP only)
+    float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [steps][LS]
+    for (int t = threadIdx.x; t < CINP * 16; t += 256) s_root[t] = root[t];
+    if (SKIP) for (int t = threadIdx.x; t < 20 * 16; t += 256) s_skip[t] = wskip[t];
+    if (LUT_IN_LDS)
+        for (int t = threadIdx.x; t < steps * CINP * 16; t += 256) s_lut[(t / (CINP * 16)) * LS + t % (CINP * 16)] = lut[t];
+    __syncthreads();
+
+    const int l4 = (threadIdx.x & 3) * 4;
+    const int node = blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (node >= N) return;
+    const int d = deg[node];
+    const int* srcs = ell_src + (size_t)node * max_nb;
+    const uint16_t* stp = ell_step + (size_t)node * max_nb;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float x[CINP];
+    for (int e = 0; e < d; ++e) {
+        int s = srcs[e], c = stp[e];
+        load_row<CINP>(xin + (size_t)s * CINP, x);
+        float4 m = LUT_IN_LDS ? matvec4<CINP>(x, s_lut + c * LS + l4)
+                              : matvec4<CINP>(x, lut + (size_t)c * CINP * 16 + l4);
+        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    }
+    load_row<CINP>(xin + (size_t)node * CINP, x);
+    float4 m = matvec4<CINP>(x, s_root + l4);                                 // root weight (spline_conv.py:72-73)
+    acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    float4 sc = *(const float4*)(scale + l4), sh = *(const float4*)(shift + l4);
+    float4 y = make_float4(fmaf(acc.x, sc.x, sh.x), fmaf(acc.y, sc.y, sh.y), fmaf(acc.z, sc.z, sh.z), fmaf(acc.w, sc.w, sh.w));
+    if (SKIP) {
+        float xs[20];
+        load_row<20>(xskip + (size_t)node * 20, xs);
+        float4 k = matvec4<20>(xs, s_skip + l4);
+        float4 ks = *(const float4*)(sscale + l4), kh = *(const float4*)(sshift + l4);
+        y.x += fmaf(k.x, ks.x, kh.x); y.y += fmaf(k.y, ks.y, kh.y); y.z += fmaf(k.z, ks.z, kh.z); y.w += fmaf(k.w, ks.w, kh.w);
+    }
+    y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+    *(float4*)(out + (size_t)node * 16 + l4) = y;
+}
+
+template <int CINP, bool SKIP>
+static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_step, const int* deg, const float* lut,
+                     const float* root, const float* scale, const float* shift, const float* xskip, const float* wskip,
+                     const float* sscale, const float* sshift, float* out, int N, int steps, int max_nb, hipStream_t st) {
+    constexpr int LS = CINP * 16 + 16;
+    size_t fixed = sizeof(float) * (CINP * 16 + (SKIP ? 320 : 0));
+    size_t with_lut = fixed + sizeof(float) * (size_t)steps * LS;
+    dim3 grid(evad_blocks(N, 64)), block(256);
+    if (with_lut <= 80 * 1024) {            // two workgroups per CU (160 KiB LDS)
+        auto kern = k_l1_conv<CINP, SKIP, true>;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)with_lut);
+        hipLaunchKernelGGL(kern, grid, block, with_lut, st, xin, ell_src, ell_step, deg, lut, root, scale, shift, xskip,
+                           wskip, sscale, sshift, out, N, steps, max_nb);
+    } else {                                // large radius: LUT stays in global memory / L2
+        auto kern = k_l1_conv<CINP, SKIP, false>;
+        hipLaunchKernelGGL(kern, grid, block, fixed, st, xin, ell_src, ell_step, deg, lut, root, scale, shift, xskip,
+                           wskip, sscale, sshift, out, N, steps, max_nb);
+    }
+    return evad_last_error();
+}
+
+// conv 1: x0s[N,20] (19 channels + pad) -> y1[N,16]
+extern "C" int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
+                                const float* lut /* [steps][20][16] */, const float* root /* [20][16] */,
+                                const float* bn_scale, const float* bn_shift, float* y1, int N, int steps,
+                                int max_num_neighbors, void* stream) {
+    if (!x0s || !ell_src || !ell_step || !deg || !lut || !root || !bn_scale || !bn_shift || !y1 || N < 0 || steps < 1)
+        return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    return launch_l1<20, false>(x0s, ell_src, ell_step, deg, lut, root, bn_scale, bn_shift, nullptr, nullptr, nullptr,
+                                nullptr, y1, N, steps, max_num_neighbors, (hipStream_t)stream);
+}
+
+// conv 2 + skip branch: y1[N,16], x0s[N,20] -> y2[N,16]
+extern "C" int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t* ell_src, const uint16_t* ell_step,
+                                const int32_t* deg, const float* lut /* [steps][16][16] */, const float* root /* [16][16] */,
+                                const float* bn_scale, const float* bn_shift, const float* wskip /* [20][16] */,
+                                const float* skip_scale, const float* skip_shift, float* y2, int N, int steps,
+                                int max_num_neighbors, void* stream) {
+    if (!y1 || !x0s || !ell_src || !ell_step || !deg || !lut || !root || !bn_scale || !bn_shift || !wskip ||
+        !skip_scale || !skip_shift || !y2 || N < 0 || steps < 1)
+        return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    return launch_l1<16, true>(y1, ell_src, ell_step, deg, lut, root, bn_scale, bn_shift, x0s, wskip, skip_scale,
+                               skip_shift, y2, N, steps, max_num_neighbors, (hipStream_t)stream);
+}

@@ -1,0 +1,302 @@
+// eventad_amd/csrc/pool.hip -- voxel-grid pooling (reference src/dagr/model/layers/pooling.py:51-97)
+// fused with the image-feature sampling that precedes it (sampling_skip, net.py:15-17,200-228).
+//
+// Reference: cluster = grid_cluster([x,y,t,b]) -> sorted unique relabel -> scatter_max / mean of
+// x, mean of pos (floored to the pixel grid), batch[perm], cluster[edge_index] minus self loops,
+// unique(dim=-1).  Natively the cluster id IS an index into a dense voxel-slot table
+//      slot = cx + nx*cy + nx*ny*(batch + tcell),   S = nx*ny*(B+1) slots
+// (tcell = (int)pos_t is 1 only for events at t == time_window: the reference's "last event lands
+// in the next clip's voxel" quirk, SURVEY.md section 5, reproduced here), so:
+//   pool_scatter   one pass over the nodes: sample the CNN map, atomic max (order-preserving uint
+//                  encoding) or float add into the slot's feature row, integer pixel sums, count,
+//                  max member index (= the reference's perm on CPU);
+//   pool_finalize  occupancy scan -> consecutive node ids in ascending slot order (= sorted unique),
+//                  decode features, mean position -> pixel grid, batch, next layer's input row
+//                  [features | pos_x | pos_y];
+//   pool_edges_*   every input edge sets one bit in its destination slot's 5x5x3 neighbour-window
+//                  bitmap (dedup for free); emit walks the bits in ascending slot order, which is
+//                  ascending source id = the reference's unique(dim=-1) order within a destination.
+#include "common.h"
+
+__device__ __forceinline__ void bilin_setup(float px_norm, float py_norm, float Wf, float Hf, int w_in, int h_in,
+                                            int* x0, int* y0, float* fx, float* fy) {
+    float x = __fmul_rn(px_norm, Wf), y = __fmul_rn(py_norm, Hf);
+    float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, x), Wf - 1.f), 1.f);
+    float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, y), Hf - 1.f), 1.f);
+    float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.f), 2.f), (float)(w_in - 1));
+    float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yn, 1.f), 2.f), (float)(h_in - 1));
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    *x0 = (int)fx0; *y0 = (int)fy0; *fx = ix - fx0; *fy = iy - fy0;
+}
+
+// 16 lanes per node, 16 nodes per 256-thread block.
+template <bool MEAN>
+__global__ __launch_bounds__(256) void k_pool_scatter(
+    const float* __restrict__ xa, int lda, int Ca, const float* __restrict__ map, int map_h, int map_w, int Cm,
+    const float* __restrict__ npos, const int* __restrict__ npix, const int* __restrict__ nbatch,
+    const int* __restrict__ key_s, const int* __restrict__ nidx, int n_max, const int* __restrict__ n_dev,
+    int W, int H, float vsx, float vsy, int nx, int ny, int S,
+    unsigned* __restrict__ feat, unsigned long long* __restrict__ sums, float* __restrict__ tsum,
+    unsigned* __restrict__ cnt, int* __restrict__ maxidx, int* __restrict__ node_slot, unsigned* __restrict__ flags) {
+    const int n = n_dev ? min(*n_dev, n_max) : n_max;
+    const int node = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int lane = threadIdx.x & 15;
+    if (node >= n) return;
+    const float px = npos[3 * node], py = npos[3 * node + 1], pt = npos[3 * node + 2];
+    int b, ipx, ipy;
+    if (key_s) { int k = key_s[node]; ipx = k % W; ipy = (k / W) % H; b = k / (W * H); }
+    else       { ipx = npix[2 * node]; ipy = npix[2 * node + 1]; b = nbatch[node]; }
+    // grid_cluster (torch_cluster): c_d = (int64)((pos_d - 0) / size_d)
+    int cx = (int)__fdiv_rn(px, vsx), cy = (int)__fdiv_rn(py, vsy), ct = (int)pt;
+    long long slot_ll = (long long)cx + (long long)nx * cy + (long long)nx * ny * (b + ct);
+    if (slot_ll < 0 || slot_ll >= S) { if (lane == 0) atomicOr(flags, EVAD_FLAG_POOL_WINDOW); slot_ll = slot_ll < 0 ? 0 : S - 1; }
+    const int slot = (int)slot_ll;
+    const int C = Ca + Cm;
+    unsigned* frow = feat + (size_t)slot * C;
+    for (int c = lane; c < Ca; c += 16) {
+        float v = xa[(size_t)node * lda + c];
+        if (MEAN) atomicAdd((float*)frow + c, v); else atomicMax(frow + c, evad_f2ord(v));
+    }
+    if (Cm > 0) {
+        int x0, y0; float fx, fy;
+        bilin_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+        float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
+        bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
+        const float* m = map + (size_t)b * map_h * map_w * Cm;
+        const float* p00 = m + ((size_t)y0 * map_w + x0) * Cm;
+        const float* p01 = p00 + Cm;
+        const float* p10 = p00 + (size_t)map_w * Cm;
+        const float* p11 = p10 + Cm;
+        for (int c = lane; c < Cm; c += 16) {
+            float v = 0.f;
+            if (vx0 && vy0) v += p00[c] * w00;
+            if (vx1 && vy0) v += p01[c] * w01;
+            if (vx0 && vy1) v += p10[c] * w10;
+            if (vx1 && vy1) v += p11[c] * w11;
+            if (MEAN) atomicAdd((float*)frow + Ca + c, v); else atomicMax(frow + Ca + c, evad_f2ord(v));
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&sums[2 * (size_t)slot], (unsigned long long)ipx);
+        atomicAdd(&sums[2 * (size_t)slot + 1], (unsigned long long)ipy);
+        atomicAdd(&tsum[slot], pt);
+        atomicAdd(&cnt[slot], 1u);
+        atomicMax(&maxidx[slot], nidx ? nidx[node] : node);
+        node_slot[node] = slot;
+    }
+}
+
+extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
+                                    const float* npos, const int32_t* npix, const int32_t* nbatch, const int32_t* key_s,
+                                    const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx,
+                                    float vsy, int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums,
+                                    float* tsum, uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags,
+                                    void* stream) {
+    if (!xa || !npos || !feat || !sums || !tsum || !cnt || !maxidx || !node_slot || !flags || (!key_s && (!npix || !nbatch)) ||
+        (Cm > 0 && !map_nhwc) || Ca < 0 || Cm < 0 || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0 || vsx <= 0 || vsy <= 0)
+        return EVAD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int S = nx * ny * (B + 1), C = Ca + Cm;
+    hipMemsetAsync(feat, 0, sizeof(uint32_t) * (size_t)S * C, st);
+    hipMemsetAsync(sums, 0, sizeof(uint64_t) * 2 * (size_t)S, st);
+    hipMemsetAsync(tsum, 0, sizeof(float) * (size_t)S, st);
+    hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)S, st);
+    hipMemsetAsync(maxidx, 0xFF, sizeof(int32_t) * (size_t)S, st);
+    if (n_max == 0) return evad_last_error();
+    dim3 grid(evad_blocks(n_max, 16)), block(256);
+    if (mean_aggr)
+        hipLaunchKernelGGL(k_pool_scatter<true>, grid, block, 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, npix,
+                           nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
+                           tsum, cnt, maxidx, node_slot, flags);
+    else
+        hipLaunchKernelGGL(k_pool_scatter<false>, grid, block, 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, npix,
+                           nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
+                           tsum, cnt, maxidx, node_slot, flags);
+    return evad_last_error();
+}
+
+// --------------------------------------------------------------------------- finalize
+int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, hipStream_t st);
+
+__global__ void k_occupancy(const unsigned* __restrict__ cnt, unsigned* __restrict__ occ, int S) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) occ[s] = cnt[s] > 0 ? 1u : 0u;
+}
+
+__global__ void k_finalize_nodes(const unsigned* __restrict__ occ_scan, const unsigned* __restrict__ cnt,
+                                 const unsigned long long* __restrict__ sums, const float* __restrict__ tsum,
+                                 const int* __restrict__ maxidx, const int* __restrict__ batch_of_index, int S, int level0,
+                                 float Wf, float Hf, float whx, float why, int C, int ldx, float* __restrict__ xout,
+                                 float* __restrict__ npos, int* __restrict__ npix, int* __restrict__ nbatch,
+                                 int* __restrict__ node_slot_out, int* __restrict__ slot2node, int* __restrict__ n_out) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) *n_out = (int)occ_scan[S];
+    if (s >= S) return;
+    unsigned c = cnt[s];
+    if (c == 0) { slot2node[s] = -1; return; }
+    int j = (int)occ_scan[s];
+    slot2node[s] = j; node_slot_out[j] = s;
+    // pool_pos: mean of the members' normalised positions.  Level 0: pos = px/W; pooled levels:
+    // pos = q * (1/W) (round_to_pixel).  Integer pixel sums make the mean order independent.
+    float sx = (float)sums[2 * (size_t)s], sy = (float)sums[2 * (size_t)s + 1];
+    float fx = level0 ? __fdiv_rn(sx, Wf) : __fmul_rn(sx, whx);
+    float fy = level0 ? __fdiv_rn(sy, Hf) : __fmul_rn(sy, why);
+    float cf = (float)c;
+    float mx = __fdiv_rn(fx, cf), my = __fdiv_rn(fy, cf), mt = __fdiv_rn(tsum[s], cf);
+    // round_to_pixel (pooling.py:47-49): floor((p + 1e-5) / wh_inv) * wh_inv
+    float qx = floorf(__fdiv_rn(__fadd_rn(mx, 1e-5f), whx)), qy = floorf(__fdiv_rn(__fadd_rn(my, 1e-5f), why));
+    float ox = __fmul_rn(qx, whx), oy = __fmul_rn(qy, why);
+    npos[3 * j] = ox; npos[3 * j + 1] = oy; npos[3 * j + 2] = mt;
+    npix[2 * j] = (int)qx; npix[2 * j + 1] = (int)qy;
+    nbatch[j] = batch_of_index[maxidx[s]];
+    xout[(size_t)j * ldx + C] = ox; xout[(size_t)j * ldx + C + 1] = oy;
+    for (int k = C + 2; k < ldx; ++k) xout[(size_t)j * ldx + k] = 0.f;
+}
+
+template <bool MEAN>
+__global__ void k_finalize_feat(const unsigned* __restrict__ feat, const unsigned* __restrict__ cnt,
+                                const int* __restrict__ slot2node, int S, int C, int ldx, float* __restrict__ xout) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)S * C) return;
+    int s = (int)(t / C), c = (int)(t % C);
+    int j = slot2node[s];
+    if (j < 0) return;
+    float v = MEAN ? __fdiv_rn(__uint_as_float(feat[t]), (float)cnt[s]) : evad_ord2f(feat[t]);
+    xout[(size_t)j * ldx + c] = v;
+}
+
+extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const float* tsum, const uint32_t* cnt,
+                                     const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
+                                     int mean_aggr, int level0, int W, int H, float wh_inv_x, float wh_inv_y,
+                                     uint32_t* occ_scan, uint32_t* scan_tmp, float* xout, int ldx, float* npos_out,
+                                     int32_t* npix_out, int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node,
+                                     int32_t* n_out_dev, void* stream) {
+    if (!feat || !sums || !tsum || !cnt || !maxidx || !batch_of_index || !occ_scan || !scan_tmp || !xout || !npos_out ||
+        !npix_out || !nbatch_out || !node_slot_out || !slot2node || !n_out_dev || ldx < C + 2 || nx <= 0 || ny <= 0 || B <= 0)
+        return EVAD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int S = nx * ny * (B + 1);
+    hipLaunchKernelGGL(k_occupancy, dim3(evad_blocks(S, 256)), dim3(256), 0, st, cnt, occ_scan, S);
+    int rc = evad_exclusive_scan(occ_scan, occ_scan, scan_tmp, S, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_finalize_nodes, dim3(evad_blocks(S, 256)), dim3(256), 0, st, occ_scan, cnt,
+                       (const unsigned long long*)sums, tsum, maxidx, batch_of_index, S, level0, (float)W, (float)H,
+                       wh_inv_x, wh_inv_y, C, ldx, xout, npos_out, npix_out, nbatch_out, node_slot_out, slot2node, n_out_dev);
+    dim3 grid(evad_blocks((long long)S * C, 256));
+    if (mean_aggr) hipLaunchKernelGGL(k_finalize_feat<true>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
+    else           hipLaunchKernelGGL(k_finalize_feat<false>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
+    return evad_last_error();
+}
+
+// --------------------------------------------------------------------------- pooled edges
+// bit index of a source slot relative to its destination slot: ((dp+1)*5 + (dy+2))*5 + (dx+2)
+__device__ __forceinline__ void mark_edge(int ss, int sd, int nx, int ny, unsigned* __restrict__ bitmap, unsigned* flags) {
+    if (ss == sd) return;                                   // self loop after clustering: dropped (pooling.py:62-64)
+    int plane = nx * ny;
+    int dx = ss % nx - sd % nx, dy = (ss / nx) % ny - (sd / nx) % ny, dp = ss / plane - sd / plane;
+    if (dx < -2 || dx > 2 || dy < -2 || dy > 2 || dp < -1 || dp > 1) { atomicOr(flags, EVAD_FLAG_POOL_WINDOW); return; }
+    int bit = ((dp + 1) * 5 + (dy + 2)) * 5 + (dx + 2);
+    unsigned* w = bitmap + (size_t)sd * 3 + (bit >> 5);
+    unsigned m = 1u << (bit & 31);
+    if (!(*(volatile unsigned*)w & m)) atomicOr(w, m);
+}
+
+__global__ void k_mark_ell(const int* __restrict__ ell_src, const int* __restrict__ deg, const int* __restrict__ node_slot,
+                           int N, int max_nb, int nx, int ny, unsigned* __restrict__ bitmap, unsigned* __restrict__ flags) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * max_nb) return;
+    int r = (int)(t / max_nb), k = (int)(t % max_nb);
+    if (k == 0 || k >= deg[r]) return;
+    mark_edge(node_slot[ell_src[t]], node_slot[r], nx, ny, bitmap, flags);
+}
+
+__global__ void k_mark_csr(const unsigned* __restrict__ rowptr, const int* __restrict__ csr_src,
+                           const int* __restrict__ node_slot, int n_max, const int* __restrict__ n_dev, int nx, int ny,
+                           unsigned* __restrict__ bitmap, unsigned* __restrict__ flags) {
+    // one 16-lane group per destination node
+    int n = min(*n_dev, n_max);
+    int node = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+    if (node >= n) return;
+    int sd = node_slot[node];
+    for (unsigned e = rowptr[node] + lane; e < rowptr[node + 1]; e += 16) mark_edge(node_slot[csr_src[e]], sd, nx, ny, bitmap, flags);
+}
+
+__global__ void k_edge_count(const unsigned* __restrict__ bitmap, const int* __restrict__ node_slot_out, int n_max,
+                             const int* __restrict__ n_dev, unsigned* __restrict__ degree) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_max) return;
+    int n = min(*n_dev, n_max);
+    unsigned d = 0;
+    if (j < n) { const unsigned* w = bitmap + (size_t)node_slot_out[j] * 3; d = __popc(w[0]) + __popc(w[1]) + __popc(w[2]); }
+    degree[j] = d;
+}
+
+__global__ void k_edge_emit(const unsigned* __restrict__ bitmap, const int* __restrict__ node_slot_out,
+                            const int* __restrict__ slot2node, const int* __restrict__ npix, int n_max,
+                            const int* __restrict__ n_dev, int nx, int ny, const unsigned* __restrict__ rowptr,
+                            int* __restrict__ csr_src, int* __restrict__ csr_dxy, int* __restrict__ e_out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = min(*n_dev, n_max);
+    if (j == 0) *e_out = (int)rowptr[n];
+    if (j >= n) return;
+    int sd = node_slot_out[j];
+    const unsigned* w = bitmap + (size_t)sd * 3;
+    unsigned o = rowptr[j];
+    int pxd = npix[2 * j], pyd = npix[2 * j + 1];
+    for (int word = 0; word < 3; ++word) {
+        unsigned bits = w[word];
+        while (bits) {
+            int bit = __ffs(bits) - 1 + word * 32;
+            bits &= bits - 1;
+            int dx = bit % 5 - 2, dy = (bit / 5) % 5 - 2, dp = bit / 25 - 1;
+            int src = slot2node[sd + dx + nx * dy + nx * ny * dp];
+            csr_src[o] = src;
+            int ddx = npix[2 * src] - pxd, ddy = npix[2 * src + 1] - pyd;       // pos[src] - pos[dst] in pixels
+            csr_dxy[o] = (ddx & 0xffff) | (ddy << 16);
+            ++o;
+        }
+    }
+}
+
+extern "C" int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t* deg, const int32_t* node_slot, int N,
+                                           int max_num_neighbors, int nx, int ny, int B, uint32_t* bitmap, uint32_t* flags,
+                                           void* stream) {
+    if (!ell_src || !deg || !node_slot || !bitmap || !flags || N < 0 || nx <= 0 || ny <= 0 || B <= 0) return EVAD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    if (N > 0)
+        hipLaunchKernelGGL(k_mark_ell, dim3(evad_blocks((long long)N * max_num_neighbors, 256)), dim3(256), 0, st, ell_src,
+                           deg, node_slot, N, max_num_neighbors, nx, ny, bitmap, flags);
+    return evad_last_error();
+}
+
+extern "C" int eventad_pool_edges_mark_csr(const uint32_t* rowptr, const int32_t* csr_src, const int32_t* node_slot,
+                                           int n_max, const int32_t* n_dev, int nx, int ny, int B, uint32_t* bitmap,
+                                           uint32_t* flags, void* stream) {
+    if (!rowptr || !csr_src || !node_slot || !n_dev || !bitmap || !flags || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0)
+        return EVAD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    if (n_max > 0)
+        hipLaunchKernelGGL(k_mark_csr, dim3(evad_blocks(n_max, 16)), dim3(256), 0, st, rowptr, csr_src, node_slot, n_max,
+                           n_dev, nx, ny, bitmap, flags);
+    return evad_last_error();
+}
+
+extern "C" int eventad_pool_edges_emit(const uint32_t* bitmap, const int32_t* node_slot_out, const int32_t* slot2node,
+                                       const int32_t* npix_out, int n_max_out, const int32_t* n_out_dev, int nx, int ny,
+                                       uint32_t* rowptr /* [n_max_out+2] */, uint32_t* scan_tmp, int32_t* csr_src,
+                                       int32_t* csr_dxy, int32_t* e_out_dev, void* stream) {
+    if (!bitmap || !node_slot_out || !slot2node || !npix_out || !n_out_dev || !rowptr || !scan_tmp || !csr_src ||
+        !csr_dxy || !e_out_dev || n_max_out < 0 || nx <= 0 || ny <= 0)
+        return EVAD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_edge_count, dim3(evad_blocks(n_max_out + 1, 256)), dim3(256), 0, st, bitmap, node_slot_out,
+                       n_max_out, n_out_dev, rowptr);
+    int rc = evad_exclusive_scan(rowptr, rowptr, scan_tmp, n_max_out + 1, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_edge_emit, dim3(evad_blocks(n_max_out > 0 ? n_max_out : 1, 256)), dim3(256), 0, st, bitmap,
+                       node_slot_out, slot2node, npix_out, n_max_out, n_out_dev, nx, ny, rowptr, csr_src, csr_dxy, e_out_dev);
+    return evad_last_error();
+}

@@ -1,0 +1,94 @@
+// eventad_amd/csrc/tail.hip -- spline convolutions on the pooled graphs (layers 2-5, <=2240 nodes/clip).
+//
+// Reference: MySplineConv with the cached LUT (src/dagr/model/layers/spline_conv.py:16-78).  Its LUTs
+// for these layers are 12 MB .. 14 GB because every integer pixel offset gets its
+// own Cin x Cout matrix.  A LUT entry is only a 4-tap blend of the 25 kernel matrices
+// (degree-1 open B-spline, torch_spline_conv basis), so natively:
+//     Z = X . [W_0 | ... | W_24 | W_root (| W_skip)]          one fp32 MFMA GEMM per conv (gemm.hip)
+//     out_i = sum_{j->i} sum_{s<4} b_s(dx,dy) * Z[j, idx_s(dx,dy)]  + Z[i, root]      (this file)
+// followed by the folded BatchNorm, the skip branch and ReLU (conv.py:23-28,47-56).
+// One wave per destination node, lane = output channel (Cout = 64 for every tail layer); edges come
+// as CSR by destination with ascending source id = the reference's edge order inside a destination.
+#include "common.h"
+
+// torch_spline_conv degree-1 basis for one pseudo-coordinate: v = attr*(kernel_size-1);
+// index k_mod in {0,1}: ((int64)v + k_mod) % 5,  weight 1 - frac - k_mod + 2*frac*k_mod.
+__device__ __forceinline__ void basis1(float attr, int* i0, int* i1, float* b0, float* b1) {
+    float v = __fmul_rn(attr, 4.f);
+    int t = (int)v;                                    // truncation, as the (int64_t) cast
+    float fr = __fsub_rn(v, floorf(v));
+    int a = t % 5, b = (t + 1) % 5;
+    *i0 = a < 0 ? a + 5 : a; *i1 = b < 0 ? b + 5 : b;  // advanced indexing wraps negative indices
+    *b0 = __fsub_rn(1.f, fr);
+    *b1 = __fadd_rn(__fsub_rn(__fsub_rn(1.f, fr), 1.f), __fmul_rn(2.f, fr));
+}
+
+__global__ __launch_bounds__(256) void k_tail_blend(const float* __restrict__ Z, int ldz, int root_col,
+                                                    const float* __restrict__ Zs, int ldzs, int skip_col,
+                                                    const unsigned* __restrict__ rowptr, const int* __restrict__ csr_src,
+                                                    const int* __restrict__ csr_dxy, int n_max, const int* __restrict__ n_dev,
+                                                    float div_x, float div_y, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const float* __restrict__ sscale,
+                                                    const float* __restrict__ sshift, float* __restrict__ out, int ldo,
+                                                    int ld_pad_to) {
+    const int n = min(*n_dev, n_max);
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    if (node >= n) return;
+    float acc = 0.f;
+    const unsigned e0 = rowptr[node], e1 = rowptr[node + 1];
+    for (unsigned e = e0; e < e1; ++e) {
+        int s = csr_src[e], pk = csr_dxy[e];
+        int dx = (int)(short)(pk & 0xffff), dy = pk >> 16;
+        // LUT grid attribute (spline_conv.py:27-30): d / (2*M*size) + 0.5
+        float ax = __fadd_rn(__fdiv_rn((float)dx, div_x), 0.5f), ay = __fadd_rn(__fdiv_rn((float)dy, div_y), 0.5f);
+        int ix0, ix1, iy0, iy1; float bx0, bx1, by0, by1;
+        basis1(ax, &ix0, &ix1, &bx0, &bx1);
+        basis1(ay, &iy0, &iy1, &by0, &by1);
+        const float* zr = Z + (size_t)s * ldz + c;
+        float m = __fmul_rn(__fmul_rn(bx0, by0), zr[(ix0 + 5 * iy0) * 64]);
+        m = fmaf(__fmul_rn(bx1, by0), zr[(ix1 + 5 * iy0) * 64], m);
+        m = fmaf(__fmul_rn(bx0, by1), zr[(ix0 + 5 * iy1) * 64], m);
+        m = fmaf(__fmul_rn(bx1, by1), zr[(ix1 + 5 * iy1) * 64], m);
+        acc += m;
+    }
+    acc += Z[(size_t)node * ldz + root_col * 64 + c];
+    float y = fmaf(acc, scale[c], shift[c]);
+    if (Zs) y += fmaf(Zs[(size_t)node * ldzs + skip_col * 64 + c], sscale[c], sshift[c]);
+    y = fmaxf(y, 0.f);
+    out[(size_t)node * ldo + c] = y;
+    for (int k = 64 + c; k < ld_pad_to; k += 64) out[(size_t)node * ldo + k] = 0.f;
+}
+
+extern "C" int eventad_tail_blend(const float* Z, int ldz, int root_col, const float* Zskip, int ldzs, int skip_col,
+                                  const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,
+                                  const int32_t* n_dev, float div_x, float div_y, const float* bn_scale,
+                                  const float* bn_shift, const float* skip_scale, const float* skip_shift, float* out,
+                                  int ldo, void* stream) {
+    if (!Z || !rowptr || !csr_src || !csr_dxy || !n_dev || !bn_scale || !bn_shift || !out || n_max < 0 || ldo < 64 ||
+        div_x <= 0 || div_y <= 0 || (Zskip && (!skip_scale || !skip_shift)))
+        return EVAD_ERR_ARG;
+    if (n_max == 0) return EVAD_OK;
+    hipLaunchKernelGGL(k_tail_blend, dim3(evad_blocks(n_max, 4)), dim3(256), 0, (hipStream_t)stream, Z, ldz, root_col,
+                       Zskip, ldzs, skip_col, rowptr, csr_src, csr_dxy, n_max, n_dev, div_x, div_y, bn_scale, bn_shift,
+                       skip_scale, skip_shift, out, ldo, 64);
+    return evad_last_error();
+}
+
+// NCHW -> NHWC for externally supplied ("precomputed") CNN feature maps: out[b,p,c] = in[b,c,p]
+__global__ void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int P, long long total) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int c = (int)(t % C);
+    long long bp = t / C;
+    int p = (int)(bp % P);
+    long long b = bp / P;
+    out[t] = in[(b * C + c) * (long long)P + p];
+}
+
+extern "C" int eventad_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream) {
+    if (!in || !out || B < 0 || C <= 0 || H <= 0 || W <= 0) return EVAD_ERR_ARG;
+    long long total = (long long)B * C * H * W;
+    if (total == 0) return EVAD_OK;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(evad_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, total);
+    return evad_last_error();
+}

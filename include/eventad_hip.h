@@ -1,0 +1,129 @@
+/*
+ * include/eventad_hip.h -- C ABI of libeventad_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the EventAD hot path.  The reference has no C plugin ABI:
+ * its only native piece is the pybind11 torch extension `ev_graph_cuda`
+ * (reference src/dagr/graph/ev_graph.cu:279-283).  Group (A) below are exactly those three
+ * functions with torch tensors replaced by raw device pointers + sizes + a stream; groups (B)-(E)
+ * are the native stage functions the Python host mirror (eventad_amd/) drives for the rest of the
+ * path, each citing the reference code it replaces.
+ *
+ * Conventions: every pointer is DEVICE memory owned by the caller unless it says "host"; nothing
+ * is allocated or freed per call (one small cached spiral table excepted); every launch goes on
+ * `stream` (a hipStream_t passed as void*); no call synchronises the stream, so all of them can be
+ * captured into a hipGraph after one warm-up call.  Return value: 0 = launched, -1 = bad argument
+ * (the reference raises RuntimeError via AT_ASSERTM, ev_graph.cu:9-12), other = hipError_t.
+ * Data-dependent problems (timestamps not monotone, event outside the sensor, pooled edge outside
+ * the neighbour window) are reported through a caller-owned `flags` word, see EVENTAD_FLAG_*.
+ */
+#ifndef EVENTAD_HIP_H
+#define EVENTAD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVENTAD_FLAG_T_NOT_MONOTONE 1u
+#define EVENTAD_FLAG_POS_OUT_OF_FOV 2u
+#define EVENTAD_FLAG_POOL_WINDOW    4u
+#define EVENTAD_FLAG_T_OUT_OF_RANGE 8u
+
+/* ---- (A) reference-compatible graph builder: replaces pybind module ev_graph_cuda ------------- */
+/* insert_in_queue_cuda(indices, unique_coords, cumsum_counts, queue)   ev_graph.cu:241-276 (kernel :169-212)
+ * indices i32[N] ids sorted by pixel, unique_coords i32[K], cumsum_counts i32[K], queue i32[B,Q,H,W] in place. */
+int eventad_insert_in_queue(const int32_t* indices, const int32_t* unique_coords, const int32_t* cumsum_counts,
+                            int32_t* queue, int B, int Q, int H, int W, int K, void* stream);
+/* insert_in_queue_single_cuda(indices, events, queue)                  ev_graph.cu:215-238 (kernel :130-166) */
+int eventad_insert_in_queue_single(const int32_t* indices, const int32_t* events, int32_t* queue,
+                                   int B, int Q, int H, int W, void* stream);
+/* fill_edges_cuda(batch, pos, all_timestamps, event_queue, indices, max_num_neighbors, radius, delta_t_us,
+ *                 edges, min_index)                                     ev_graph.cu:82-128 (kernel :15-80)
+ * edges i64[2,K] prefilled with -1 by the caller (ev_graph.py:89), K >= N*max_num_neighbors. */
+int eventad_fill_edges(const int32_t* batch, const int32_t* pos, const int32_t* all_timestamps,
+                       const int32_t* event_queue, const int32_t* indices, int max_num_neighbors, float radius,
+                       float delta_t_us, int64_t* edges, int min_index, int B, int Q, int H, int W, int N, int64_t K,
+                       void* stream);
+/* spiral.h:1-15 as a table; dxdy is HOST memory int16[(2r+1)^2][2]; returns the number of steps. */
+int eventad_spiral_offsets(int radius, int16_t* dxdy);
+
+/* ---- (B) native graph build: replaces EV_TGN.forward + SlidingWindowGraph.forward ------------- */
+/* (ev_tgn.py:39-58, ev_graph.py:62-103, graph/utils.py:6-23) for one fresh batch.
+ * eventad_sort_events: denormalise (ev_tgn.py:11-16), counting-sort the events by pixel, and emit
+ * sorted-order records plus the 19(+1 pad)-channel layer-1 input row x0s[r] =
+ * [polarity, 16 bilinear samples of CNN map 0 (net.py:116,200-228), pos_x, pos_y, 0].
+ *   in : pos f32[N,3] normalised, batch i64[N], polarity f32[N], map0 f32[B,h,w,16] (NHWC)
+ *   out: key/tq/bev i32[N] (event order: pixel key, t in us, clip), pix_start u32[B*H*W+1],
+ *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], posn_s f32[N,3], x0s f32[N,20]
+ *   ws : pix_count u32[B*H*W+1], scan_tmp u32[B*H*W/2048+2], sid_tmp i32[N], long_list i32[B*H*W],
+ *        counters u32[4] ([0] = EVENTAD_FLAG_* bits, caller zeroes it; [1] internal) */
+int eventad_sort_events(const float* pos, const int64_t* batch, const float* polarity, const float* map0_nhwc,
+                        int map_h, int map_w, int N, int B, int W, int H, int T, int32_t* key, int32_t* tq,
+                        int32_t* bev, uint32_t* pix_count, uint32_t* pix_start, uint32_t* scan_tmp, int32_t* sid_tmp,
+                        int32_t* sid, int32_t* long_list, uint32_t* counters, int32_t* key_s, int32_t* ts_s,
+                        float* posn_s, float* x0s, void* stream);
+/* eventad_build_ell: the edge search of ev_graph.cu:15-80 over the pixel CSR.  ELL adjacency in
+ * pixel-sorted numbering: ell_src i32[N,K] (slot 0 = self edge), ell_step u16[N,K] (spiral step =
+ * LUT cell of the source pixel), deg i32[N]. */
+int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* key_s, const uint32_t* pix_start,
+                      const uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
+                      int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step, int32_t* deg,
+                      void* stream);
+/* ELL -> the reference's edge buffer layout (i64[2,K], event numbering, -1 padded). */
+int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32_t* sid, int N, int max_num_neighbors,
+                         int64_t K, int64_t* edges, void* stream);
+int eventad_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, int64_t n, void* stream);
+
+/* ---- (C) first Layer on the event graph: replaces Layer.forward for conv_block1 --------------- */
+/* (conv.py:59-72 = ConvBlock :10-28 + ConvBlockWithSkip :31-56 over MySplineConv.message_lut,
+ * spline_conv.py:39-78).  lut = MySplineConv.lut_weights re-ordered by spiral step, [steps][Cin_pad][16];
+ * root = conv.lin.weight^T [Cin_pad][16]; bn_* = folded eval BatchNorm (components.py:9-12). */
+int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
+                     const float* lut, const float* root, const float* bn_scale, const float* bn_shift, float* y1,
+                     int N, int steps, int max_num_neighbors, void* stream);
+int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t* ell_src, const uint16_t* ell_step,
+                     const int32_t* deg, const float* lut, const float* root, const float* bn_scale,
+                     const float* bn_shift, const float* wskip, const float* skip_scale, const float* skip_shift,
+                     float* y2, int N, int steps, int max_num_neighbors, void* stream);
+
+/* ---- (D) sampling_skip + Pooling.forward: replaces net.py:15-17,200-228 + pooling.py:51-97 ------ */
+/* Slot table over S = nx*ny*(B+1) voxel slots: feat u32[S,Ca+Cm], sums u64[S,2], tsum f32[S],
+ * cnt u32[S], maxidx i32[S].  Level 0 passes key_s (pixel keys) and nidx = sid; pooled levels pass
+ * npix/nbatch and n_dev (device-side node count). */
+int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
+                         const float* npos, const int32_t* npix, const int32_t* nbatch, const int32_t* key_s,
+                         const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx, float vsy,
+                         int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums, float* tsum,
+                         uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, void* stream);
+int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const float* tsum, const uint32_t* cnt,
+                          const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
+                          int mean_aggr, int level0, int W, int H, float wh_inv_x, float wh_inv_y, uint32_t* occ_scan,
+                          uint32_t* scan_tmp, float* xout, int ldx, float* npos_out, int32_t* npix_out,
+                          int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node, int32_t* n_out_dev,
+                          void* stream);
+int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t* deg, const int32_t* node_slot, int N,
+                                int max_num_neighbors, int nx, int ny, int B, uint32_t* bitmap, uint32_t* flags,
+                                void* stream);
+int eventad_pool_edges_mark_csr(const uint32_t* rowptr, const int32_t* csr_src, const int32_t* node_slot, int n_max,
+                                const int32_t* n_dev, int nx, int ny, int B, uint32_t* bitmap, uint32_t* flags,
+                                void* stream);
+int eventad_pool_edges_emit(const uint32_t* bitmap, const int32_t* node_slot_out, const int32_t* slot2node,
+                            const int32_t* npix_out, int n_max_out, const int32_t* n_out_dev, int nx, int ny,
+                            uint32_t* rowptr, uint32_t* scan_tmp, int32_t* csr_src, int32_t* csr_dxy,
+                            int32_t* e_out_dev, void* stream);
+
+/* ---- (E) dense pieces: tail Layers (conv.py:59-72 on pooled graphs), 1x1 reducers ------------- */
+/* C = epilogue(A.B): exact-fp32 MFMA GEMM; m_dev (nullable) = device-side row count <= M. */
+int eventad_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, const int32_t* m_dev,
+                     int N, int K, const float* bias, const float* scale, const float* shift, const float* residual,
+                     int ldr, int relu, void* stream);
+/* out_i = ReLU(BN(sum_e sum_taps b*Z[src, cell] + Z[i, root]) [+ BN_skip(Zskip[i, skip])]), Cout = 64. */
+int eventad_tail_blend(const float* Z, int ldz, int root_col, const float* Zskip, int ldzs, int skip_col,
+                       const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,
+                       const int32_t* n_dev, float div_x, float div_y, const float* bn_scale, const float* bn_shift,
+                       const float* skip_scale, const float* skip_shift, float* out, int ldo, void* stream);
+int eventad_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,125 @@
+"""GPU parity: native HIP backbone (through the C ABI) vs the CPU oracle on the same seeded input."""
+import pytest
+import torch
+
+from eventad_amd import synthetic, weights
+from eventad_amd._lib import call, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(W, H, n, B, t_span_us=50000):
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    data = synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True, t_span_us=t_span_us)
+    data = dagr_ref.format_data(data)
+    sd = weights.random_graph_state()
+    cfg = dagr_ref.make_config(W, H, B)
+    (o3, o4), stages = dagr_ref.backbone_forward(sd, data, cfg, data.image_feats, return_all=True)
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(sd, W, H, dev)
+    res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    torch.cuda.synchronize()
+    assert nb.check_flags() & ~1 == 0
+    return data, cfg, (o3, o4), stages, nb, res
+
+
+def _level(L):
+    n = int(L.n_dev.item())
+    e = int(L.e_dev.item())
+    rowptr = L.rowptr[: n + 1].cpu().long()
+    src = L.csr_src[:e].cpu().long()
+    dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    return n, L.x[:n].cpu(), L.npos[:n].cpu(), L.nbatch[:n].cpu().long(), torch.stack([src, dst])
+
+
+CASES = [(64, 64, 3000, 2, 50000), (256, 256, 20000, 3, 50000), (256, 256, 6000, 2, 400000)]
+
+
+@pytest.mark.parametrize("W,H,n,B,span", CASES)
+def test_backbone_matches_oracle(W, H, n, B, span):
+    data, cfg, (o3, o4), stages, nb, res = _setup(W, H, n, B, span)
+    ws = res["ws"]
+    N = data.pos.shape[0]
+    # --- edges: bit exact against the oracle's edge list
+    K = 16 * N
+    edges = torch.empty((2, K), dtype=torch.int64, device="cuda")
+    call("eventad_ell_to_edges", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["sid"]), N, 16, K, ptr(edges),
+         torch.cuda.current_stream().cuda_stream)
+    edges = edges.cpu()
+    edges = edges[:, edges[1] >= 0]
+    assert torch.equal(edges, stages["edge_index0"])
+    # --- layer 1 (sorted order -> event order)
+    sid = ws["sid"].cpu().long()
+    y2 = torch.empty(N, 16)
+    y2[sid] = ws["y2"].cpu()
+    ref = stages["layer1"].x
+    assert torch.allclose(y2, ref, atol=2e-4, rtol=1e-4), float((y2 - ref).abs().max())
+    # --- pooled levels
+    for lv in range(4):
+        n_l, x, pos, batch, ei = _level(ws["levels"][lv])
+        p = stages["pool%d" % (lv + 1)]
+        assert n_l == p.x.shape[0], (lv, n_l, p.x.shape)
+        assert torch.equal(batch, p.batch)
+        C = p.x.shape[1]
+        assert torch.allclose(x[:, :C], p.x, atol=5e-4, rtol=1e-4), (lv, float((x[:, :C] - p.x).abs().max()))
+        assert torch.allclose(pos[:, :2], p.pos[:, :2], atol=1e-7) and torch.allclose(pos[:, 2], p.pos[:, 2], atol=1e-5)
+        assert torch.allclose(x[:, C:C + 2], p.pos[:, :2], atol=1e-7)
+        # oracle edges are sorted by (src,dst); native CSR is grouped by dst with ascending src
+        pe = p.edge_index
+        order = torch.argsort(pe[1] * (n_l + 1) + pe[0])
+        assert torch.equal(ei, pe[:, order]), lv
+    for name, ref_o in (("out3", o3), ("out4", o4)):
+        o = res[name]
+        n_o = int(o["n_dev"].item())
+        assert n_o == ref_o.x.shape[0]
+        got = o["x"][:n_o].cpu()
+        assert torch.allclose(got, ref_o.x, atol=1e-3, rtol=1e-3), (name, float((got - ref_o.x).abs().max()))
+        assert torch.equal(o["batch"][:n_o].cpu().long(), ref_o.batch)
+
+
+def test_reference_compatible_graph_entry_points():
+    """eventad_insert_in_queue / eventad_fill_edges (drop-in for ev_graph_cuda) == oracle, bit for bit."""
+    from oracle import graph as G
+    W = H = 32; B = 2; Q = 8; K = 16; r = 2; dt = 3000
+    data = synthetic.make_batch(W, H, 4000, B, with_image=False, t_span_us=20000)
+    pos_i = torch.stack([data.pos[:, 0].int(), data.pos[:, 1].int(), data.t.int()], 1).contiguous()
+    batch = data.batch.int()
+    g = G.SlidingWindowGraphRef(W, H, B, K, Q, r, dt)
+    want = g.forward(batch, pos_i)
+    N = len(batch)
+    dev = "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    lin = pos_i[:, 0] + W * pos_i[:, 1] + W * H * batch
+    s_lin, s_idx = torch.sort(lin, stable=True)
+    uniq, counts = torch.unique_consecutive(s_lin, return_counts=True)
+    indices = torch.arange(N, dtype=torch.int32)
+    d = lambda t: t.contiguous().to(dev)
+    queue = torch.full((B, Q, H, W), -1, dtype=torch.int32, device=dev)
+    si, uq, cs = d(indices[s_idx]), d(uniq.int()), d(torch.cumsum(counts, 0).int())
+    call("eventad_insert_in_queue", ptr(si), ptr(uq), ptr(cs), ptr(queue), B, Q, H, W, len(uniq), st)
+    assert torch.equal(queue.cpu(), g.event_queue)
+    edges = torch.full((2, K * N), -1, dtype=torch.int64, device=dev)
+    b_d, p_d, ts_d, id_d = d(batch), d(pos_i), d(pos_i[:, 2]), d(indices)
+    call("eventad_fill_edges", ptr(b_d), ptr(p_d), ptr(ts_d), ptr(queue), ptr(id_d), K, float(r), float(dt), ptr(edges),
+         0, B, Q, H, W, N, K * N, st)
+    e = edges.cpu()
+    assert torch.equal(e[:, e[1] >= 0], want)
+    # single-event variant
+    q1 = torch.full((1, Q, H, W), -1, dtype=torch.int32, device=dev)
+    one, ev = d(torch.tensor([7], dtype=torch.int32)), d(torch.tensor([3, 5], dtype=torch.int32))
+    call("eventad_insert_in_queue_single", ptr(one), ptr(ev), ptr(q1), 1, Q, H, W, st)
+    q1 = q1.cpu()
+    assert int(q1[0, 0, 5, 3]) == 7 and int((q1 != -1).sum()) == 1
+
+
+def test_gemm_matches_torch():
+    g = torch.Generator().manual_seed(0)
+    for M, N, K in [(1000, 1728, 84), (130, 64, 64), (257, 260, 132)]:
+        A = torch.randn(M, K, generator=g).cuda()
+        Bm = torch.randn(K, N, generator=g).cuda()
+        C = torch.empty(M, N, device="cuda")
+        call("eventad_gemm_f32", ptr(A), K, ptr(Bm), N, ptr(C), N, M, None, N, K, None, None, None, None, 0, 0,
+             torch.cuda.current_stream().cuda_stream)
+        ref = (A.double() @ Bm.double()).float()
+        assert torch.allclose(C, ref, atol=1e-4, rtol=1e-4)
