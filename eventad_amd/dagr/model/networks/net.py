@@ -1,0 +1,116 @@
+"""Mirror of `dagr.model.networks.net.Net` (reference src/dagr/model/networks/net.py:30-197):
+same constructor arguments, same parameter names (conv_block1 / layer2..5 with
+conv_block{1,2}.conv.{weight,lin.weight}, norm.module.*, lin.mlp.weight, norm_skip.module.*, and
+`net.*` for the CNN branch), so reference state dicts load.  `forward` does not run torch_geometric
+layers: it hands the batch to the native HIP pipeline (eventad_amd/backbone.py)."""
+import torch
+import torch.nn as nn
+
+from ....backbone import NativeBackbone
+from ....weights import LAYER_NAMES, LAYER_DIMS
+from .net_img import HookModule
+
+
+class _Holder(nn.Module):
+    """Empty module used to build the reference's dotted parameter names."""
+    pass
+
+
+def _bn_holder(c):
+    h = _Holder()
+    h.module = nn.BatchNorm1d(c)
+    return h
+
+
+def _conv_holder(cin, cout):
+    h = _Holder()
+    h.weight = nn.Parameter(torch.empty(25, cin, cout).uniform_(-1, 1) / (4.0 * cin) ** 0.5)
+    h.lin = nn.Linear(cin, cout, bias=False)
+    return h
+
+
+class GraphOut:
+    """What the head reads of a PyG `Data` (x, pos, batch); padded device arrays + device count."""
+
+    def __init__(self, d):
+        self._d = d
+        self.n_dev = d["n_dev"]
+        self.x_padded, self.pos_padded, self.batch_padded = d["x"], d["pos"], d["batch"]
+        self._n = None
+
+    def _count(self):
+        if self._n is None:
+            self._n = int(self.n_dev.item())          # the one host sync of the API-level path
+        return self._n
+
+    @property
+    def x(self):
+        return self.x_padded[: self._count()]
+
+    @property
+    def pos(self):
+        return self.pos_padded[: self._count()]
+
+    @property
+    def batch(self):
+        return self.batch_padded[: self._count()].long()
+
+    @property
+    def edge_index(self):
+        L, n = self._d["level"], self._count()
+        e = int(L.e_dev.item())
+        rp = L.rowptr[: n + 1].long()
+        dst = torch.repeat_interleave(torch.arange(n, device=rp.device), rp[1:] - rp[:-1])
+        return torch.stack([L.csr_src[:e].long(), dst])
+
+
+class Net(nn.Module):
+    def __init__(self, args, height, width):
+        super().__init__()
+        self.height, self.width = int(height), int(width)
+        self.use_image = bool(getattr(args, "use_image", True))
+        self.num_scales = int(getattr(args, "num_scales", 2))
+        self.radius = float(args.radius)
+        self.max_neighbors = int(args.max_neighbors)
+        self.pooling_dim_at_output = str(getattr(args, "pooling_dim_at_output", "5x7"))
+        if getattr(args, "activation", "relu") != "relu" or getattr(args, "aggr", "sum") != "sum" or \
+                int(getattr(args, "kernel_size", 5)) != 5 or int(getattr(args, "edge_attr_dim", 2)) != 2:
+            raise NotImplementedError("native path implements the dagr-s configuration (relu, sum, kernel_size 5, dim 2)")
+        if not self.use_image or self.num_scales != 2:
+            raise NotImplementedError("EventAD needs use_image=True and num_scales=2 (models/EventAD.py:362)")
+        self.net = HookModule()
+        for name, (cin, cout) in zip(LAYER_NAMES, LAYER_DIMS):
+            layer = _Holder()
+            layer.conv_block1 = _Holder()
+            layer.conv_block1.conv = _conv_holder(cin, cout)
+            layer.conv_block1.norm = _bn_holder(cout)
+            layer.conv_block2 = _Holder()
+            layer.conv_block2.conv = _conv_holder(cout, cout)
+            layer.conv_block2.norm = _bn_holder(cout)
+            layer.conv_block2.lin = _Holder()
+            layer.conv_block2.lin.mlp = nn.Linear(cin, cout, bias=False)
+            layer.conv_block2.norm_skip = _bn_holder(cout)
+            setattr(self, name, layer)
+        self.out_channels = [64, 64]
+        self.out_channels_cnn = [256, 256]
+        self._native = None
+
+    def prepare(self, device=None):
+        """(Re)build the native weight images from the current parameters (called by DAGR.cache_luts)."""
+        device = device or next(self.parameters()).device
+        sd = {"backbone." + k: v for k, v in self.state_dict().items() if not k.startswith("net.")}
+        self._native = NativeBackbone(sd, self.width, self.height, device, self.radius, self.max_neighbors,
+                                      self.pooling_dim_at_output)
+        return self._native
+
+    @torch.no_grad()
+    def forward(self, data, reset=True):
+        if self._native is None:
+            self.prepare(data.pos.device)
+        feats = getattr(data, "image_feats", None)
+        nhwc = False
+        if feats is None:
+            feats, nhwc = self.net(data.image), True
+        res = self._native.forward(data.pos, data.x, data.batch, data.num_graphs, feats, feats_are_nhwc=nhwc)
+        self.last = res
+        return [GraphOut(res["out3"]), GraphOut(res["out4"])], None

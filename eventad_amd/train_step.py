@@ -1,0 +1,88 @@
+"""One optimisation step of EventAD, data-parallel over clips.
+
+Reference step body (utils/train.py:100-152, setup_optimizer :27-53): zero_grad -> forward ->
+backward (head only: the DAGR backbone is frozen and under no_grad) -> clip_grad_norm_(1.0) ->
+NaN scan -> AdamW(lr 1e-3, wd 1e-5).  Here: no `detect_anomaly`, no per-parameter host syncs (a
+non-finite gradient norm is recorded in a device flag and read lazily), and -- the one addition --
+with world_size > 1 each rank runs the reference step on its own clips and the gradients of the
+USED head parameters (852,066 floats = 3.41 MB; fusion_module.attention.* never gets a gradient)
+are summed over ranks in one flat-bucket all-reduce (RCCL over xGMI) before clipping.  Loss is the
+reference's SUM over objects, so summing gradients over ranks equals one large-batch reference step
+with per-rank hidden-state chains."""
+import torch
+import torch.distributed as dist
+
+
+class TrainStep:
+    def __init__(self, model, lr=1e-3, weight_decay=1e-5, grad_clip=1.0, process_group=None, fused=None):
+        self.model = model
+        self.grad_clip = grad_clip
+        self.params = [p for n, p in model.named_parameters()
+                       if p.requires_grad and not n.startswith("dagr_model.")]
+        self.used = [p for n, p in model.named_parameters()
+                     if p.requires_grad and not n.startswith("dagr_model.") and not n.startswith("fusion_module.attention.")]
+        dev = self.used[0].device
+        kw = {}
+        if fused is None:
+            fused = dev.type == "cuda"
+        if fused:
+            kw["fused"] = True
+        # the reference hands every parameter to AdamW (utils/train.py:38-42); parameters without a
+        # gradient are skipped by the optimiser, so only the used ones ever move
+        self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, **kw)
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.group = process_group
+        n = sum(p.numel() for p in self.used)
+        self.bucket = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.nonfinite = torch.zeros((), dtype=torch.int32, device=dev)
+        self.bucket_bytes = 4 * n
+
+    def _allreduce(self):
+        if self.world == 1:
+            return
+        off = 0
+        views = []
+        for p in self.used:
+            n = p.numel()
+            v = self.bucket[off:off + n].view_as(p)
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+            views.append(v)
+            off += n
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+        for p, v in zip(self.used, views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+    def backward_and_update(self, loss):
+        loss.backward()
+        self._allreduce()
+        norm = torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+        self.nonfinite += (~torch.isfinite(norm)).to(torch.int32)
+        self.opt.step()
+        return norm
+
+    def step(self, data, labels=None):
+        """data: formatted batch on the device.  Returns (loss, grad_norm) as device tensors."""
+        if labels is None:
+            labels = data.bbox[:, 4]
+        self.opt.zero_grad(set_to_none=True)
+        loss, logits, valid, targets = self.model.loss_only(data, labels)
+        norm = self.backward_and_update(loss)
+        return loss.detach(), norm
+
+    def step_from_feats(self, feats, data, labels=None):
+        if labels is None:
+            labels = data.bbox[:, 4]
+        self.opt.zero_grad(set_to_none=True)
+        loss, logits, valid, targets = self.model.head(feats, data, labels)
+        norm = self.backward_and_update(loss)
+        return loss.detach(), norm
+
+    def check(self):
+        if int(self.nonfinite.item()) != 0:
+            raise ValueError("non-finite gradient norm seen in a training step (reference raises at utils/train.py:147-149)")

@@ -123,6 +123,14 @@ int eventad_tail_blend(const float* Z, int ldz, int root_col, const float* Zskip
                        const float* skip_scale, const float* skip_shift, float* out, int ldo, void* stream);
 int eventad_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream);
 
+/* ---- (F) EventAD head --------------------------------------------------------------------------- */
+/* ROI pooling of out4 node features per box: replaces EventADModel.extract_features' box loop and
+ * _process_bbox (reference models/EventAD.py:382-397, 406-499).  feats f32[B,n_frames,31,64] must be
+ * zero-filled by the caller; `frame` = 1 for bbox (current), 0 for bbox0 (previous). */
+int eventad_roi_pool(const float* node_x, const float* node_pos, const int32_t* node_batch, const int32_t* n_dev,
+                     int n_max, const float* bbox, const int64_t* bbox_batch, int M, int frame, int n_frames,
+                     int width, int height, int B, float* feats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""GPU parity of the whole hot path through the reference's module API: DAGR.extract_features ->
+EventADModel.forward / one training step, against the CPU oracle on the same seeded input.
+Tolerance (BASELINE.json north_star): logits within 1e-3, argmax labels identical."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(W, H, B, n, live_cnn=False, seed=7):
+    import eventad_amd.compat as compat
+    compat.install()
+    from config.eventad_config import parse_eventad_args
+    from dagr.model.networks.dagr import DAGR
+    from dagr.model.networks.ema import ModelEMA
+    from dagr.utils.buffers import format_data
+    from models.EventAD import EventADModel
+    from eventad_amd import synthetic, weights
+    from tests.helpers import seeded_head_state
+    args = parse_eventad_args([])
+    args.batch_size = B
+    dev = torch.device("cuda:0")
+    sd = weights.random_graph_state()
+    if live_cnn:
+        sd.update(weights.random_cnn_state())
+    dagr = DAGR(args, height=H, width=W).to(dev)
+    ema = ModelEMA(dagr)
+    res = ema.ema.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and (live_cnn or all(k.startswith("backbone.net.") for k in res.missing_keys))
+    ema.ema.cache_luts(radius=args.radius, height=H, width=W)
+    model = EventADModel(ema.ema, x_dim=args.x_dim, h_dim=args.h_dim).to(dev)
+    head_sd = seeded_head_state(seed)
+    model.load_state_dict(head_sd, strict=False)
+    raw = synthetic.make_batch(W, H, n, B, with_image=live_cnn, precomputed_feats=not live_cnn)
+    data = format_data(raw.clone().to(dev))
+    return args, model, sd, head_sd, raw, data
+
+
+def _oracle(sd, head_sd, raw, W, H, B, live_cnn=False, grads=False):
+    from oracle import dagr_ref, head_ref, resnet_ref
+    d = dagr_ref.format_data(raw.clone())
+    feats_img = resnet_ref.hook_module_forward(sd, d.image) if live_cnn else d.image_feats
+    o3, o4 = dagr_ref.backbone_forward(sd, d, dagr_ref.make_config(W, H, B), feats_img)
+    p = {k: v.clone().requires_grad_(grads) for k, v in head_sd.items()}
+    feats = head_ref.roi_features(o4, d)
+    loss, outs = head_ref.head_forward(p, feats, d, d.bbox[:, 4])
+    return o4, feats, loss, outs, p
+
+
+@pytest.mark.parametrize("W,H,B,n", [(64, 64, 3, 3000), (256, 256, 4, 20000)])
+def test_forward_logits_match_oracle(W, H, B, n):
+    args, model, sd, head_sd, raw, data = _build(W, H, B, n)
+    model.eval()
+    with torch.no_grad():
+        losses, outputs, labels = model(data, data.bbox[:, 4])
+    feats_native = model.batch_feature_cache.cpu()
+    o4, feats, loss, outs, _ = _oracle(sd, head_sd, raw, W, H, B)
+    assert torch.allclose(feats_native, feats, atol=1e-3, rtol=1e-3), float((feats_native - feats).abs().max())
+    got = torch.cat([o for frame in outputs for o in frame], 0).cpu()
+    want = torch.cat([o[2] for o in outs], 0).detach()
+    assert got.shape == want.shape and len(want) > 0
+    assert float((got - want).abs().max()) < 1e-3
+    assert torch.equal(got.argmax(1), want.argmax(1))
+    assert abs(float(losses["cross_entropy"]) - float(loss)) < 1e-3 * max(1.0, float(loss))
+    tg = torch.cat([t for frame in labels for t in frame], 0).cpu()
+    assert torch.equal(tg, torch.cat([o[3] for o in outs], 0))
+
+
+def test_train_step_grads_and_update_match_oracle():
+    from eventad_amd.train_step import TrainStep
+    W = H = 64; B = 3; n = 3000
+    args, model, sd, head_sd, raw, data = _build(W, H, B, n)
+    model.eval()                                     # dropout off so the step is comparable
+    ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
+    loss, norm = ts.step(data)
+    ts.check()
+    o4, feats, oloss, outs, p = _oracle(sd, head_sd, raw, W, H, B, grads=True)
+    oloss.backward()
+    used = [k for k in p if p[k].grad is not None]
+    onorm = torch.sqrt(sum((p[k].grad ** 2).sum() for k in used))
+    assert abs(float(loss) - float(oloss)) < 1e-3 * max(1.0, float(oloss))
+    assert abs(float(norm) - float(onorm)) < 2e-3 * max(1.0, float(onorm))
+    # oracle's own AdamW step on the same (clipped) grads
+    params = [p[k] for k in used]
+    torch.nn.utils.clip_grad_norm_(params, args.grad_clip)
+    opt = torch.optim.AdamW(params, lr=args.learning_rate, weight_decay=1e-5)
+    opt.step()
+    mine = dict(model.named_parameters())
+    for k in used:
+        assert torch.allclose(mine[k].detach().cpu(), p[k].detach(), atol=2e-5, rtol=1e-4), k
+
+
+def test_live_cnn_branch_matches_oracle():
+    W = H = 64; B = 2; n = 2000
+    args, model, sd, head_sd, raw, data = _build(W, H, B, n, live_cnn=True)
+    from oracle import dagr_ref, resnet_ref
+    d = dagr_ref.format_data(raw.clone())
+    want = resnet_ref.hook_module_forward(sd, d.image)
+    got = model.dagr_model.backbone.net(data.image)
+    for g, w in zip(got, want):
+        g = g.permute(0, 3, 1, 2).cpu()
+        assert g.shape == w.shape
+        assert float((g - w).abs().max()) < 1e-3 * max(1.0, float(w.abs().max()))
+    model.eval()
+    with torch.no_grad():
+        losses, outputs, labels = model(data, data.bbox[:, 4])
+    o4, feats, loss, outs, _ = _oracle(sd, head_sd, raw, W, H, B, live_cnn=True)
+    got = torch.cat([o for frame in outputs for o in frame], 0).cpu()
+    want = torch.cat([o[2] for o in outs], 0).detach()
+    assert float((got - want).abs().max()) < 1e-3 and torch.equal(got.argmax(1), want.argmax(1))
