@@ -1,0 +1,180 @@
+"""bench.py -- EventAD hot path on MI355X: clips/sec of one optimisation step (forward of the frozen
+DAGR backbone + ROI pooling + head forward/backward + grad-clip + AdamW, = reference
+utils/train.py:100-152) on the synthetic ROL-shaped configuration BASELINE.json's metric is quoted on
+(C2: 256x256, 50k events/clip, precomputed CNN features, 8 clips per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant event-level
+kernel, HIP-event timed inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle timed on
+the host cores on the same batch)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
+
+
+def build_model(W, H, B, dev, seed=42):
+    import eventad_amd.compat as compat
+    compat.install()
+    from config.eventad_config import parse_eventad_args
+    from dagr.model.networks.dagr import DAGR
+    from dagr.model.networks.ema import ModelEMA
+    from models.EventAD import EventADModel
+    from eventad_amd import weights
+    args = parse_eventad_args([])
+    args.batch_size = B
+    torch.manual_seed(seed)
+    dagr = DAGR(args, height=H, width=W).to(dev)
+    ema = ModelEMA(dagr)
+    sd = weights.random_graph_state(seed)
+    ema.ema.load_state_dict(sd, strict=False)
+    ema.ema.cache_luts(radius=args.radius, height=H, width=W)
+    model = EventADModel(ema.ema, x_dim=args.x_dim, h_dim=args.h_dim).to(dev)
+    return args, model, sd
+
+
+def algorithmic_bytes(N, E, B, W, H):
+    """SURVEY.md 8(d) per-stage algorithmic bytes, keyed by the C-ABI call that implements the stage."""
+    maps1 = 4 * 64 * B * (H // 4) * (W // 4)
+    return {
+        "eventad_build_ell#1": 16 * N + 8 * E,                                   # S1
+        "eventad_l1_conv1#1": E * (76 + 8) + N * (76 + 64),                      # S3
+        "eventad_l1_conv2#1": E * (64 + 8) + N * (64 + 76 + 64),                 # S4
+        "eventad_pool_scatter#1": 256 * N + maps1 + N * (320 + 16) + B * 2240 * (320 + 12),   # S5 + S6
+    }
+
+
+def cpu_baseline(raw, sd, head_sd, W, H, B, steps=2, warmup=1):
+    """The CPU oracle (oracle/, kind "port") running the same optimisation step on the host cores."""
+    from oracle import dagr_ref, head_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dagr_ref.make_config(W, H, B)
+    luts = dagr_ref.cache_luts(sd, cfg)                       # one-time model set-up in the reference (dagr.py:36-71)
+    p = {k: v.clone().requires_grad_(True) for k, v in head_sd.items()}
+    params = list(p.values())
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-5)
+    d = dagr_ref.format_data(raw.clone())
+    times = []
+    for it in range(warmup + steps):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        with torch.no_grad():
+            _, o4 = dagr_ref.backbone_forward(sd, d, cfg, d.image_feats, mode="grouped", luts=luts)
+            feats = head_ref.roi_features(o4, d)
+        loss, _ = head_ref.head_forward(p, feats, d, d.bbox[:, 4])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+    sec = sum(times) / len(times)
+    return {"value": round(B / sec, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "same C2 batch (%d clips x 50k events), %d timed step(s) after %d warm-up, LUTs cached at set-up, "
+                      "torch CPU threads=%d, %.2f s/step" % (B, steps, warmup, cores, sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from eventad_amd import synthetic
+    from eventad_amd.train_step import TrainStep
+    from dagr.utils.buffers import format_data  # noqa: F401  (alias installed by build_model)
+    W, H, n_ev, B, live = synthetic.CONFIGS[a.config]
+    if live:
+        raise SystemExit("round 1 benches the precomputed-CNN-feature configurations (C2, C5)")
+    args, model, sd = build_model(W, H, B, dev)
+    from dagr.utils.buffers import format_data
+    raw = synthetic.make_config_batch(a.config, first_clip=rank * B)        # each rank owns different clips
+    data = format_data(raw.clone().to(dev))
+    model.train()                                                           # as utils/train.py:90 (dropout active)
+    ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
+    nb = model.dagr_model.backbone._native
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ts.step(data)
+    barrier()
+    if not a.no_kernel_timing:
+        nb.timing = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, norm = ts.step(data)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ts.check()
+    nb.check_flags()
+
+    if rank == 0:
+        N = int(data.pos.shape[0])
+        E = int(nb.ws["deg"].sum().item())
+        out = {
+            "metric": "clips/sec (fwd+bwd)", "value": round(world * B * a.steps / dt, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: ROL-shape %dx%d, %d events/clip + precomputed CNN feature maps, batch %d per GPU, "
+                                   "backbone fwd + head fwd/bwd + clip + AdamW" % (a.config, W, H, n_ev, B),
+                       "global_batch": world * B, "events_per_batch_per_gpu": N, "realised_edges_per_gpu": E,
+                       "parallelism": "dp%d" % world, "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
+                       "final_loss": round(float(loss), 4)},
+        }
+        if nb.timing:
+            summ = nb.timing_summary()
+            ab = algorithmic_bytes(N, E, B, W, H)
+            name = max(ab, key=lambda k: summ[k][1])
+            ms = summ[name][1]
+            ach = ab[name] / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": name.split("#")[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "algorithmic_bytes": ab[name], "avg_launch_ms": round(ms, 4)}
+            out["stage_ms"] = {k.replace("eventad_", ""): round(v[1], 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]}
+            out["backbone_ms"] = round(sum(v[1] for v in summ.values()), 4)
+        if world == 1 and not a.no_cpu_baseline:
+            head_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()
+                       if not k.startswith("dagr_model.") and not k.startswith("fusion_module.attention.")}
+            out["cpu_baseline"] = cpu_baseline(raw, sd, head_sd, W, H, B)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,6 +32,7 @@ class NativeBackbone:
         self.device = torch.device(device)
         self.prefix = prefix
         self._ws_key = None
+        self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
 
     # ------------------------------------------------------------------ weights
@@ -104,12 +105,28 @@ class NativeBackbone:
         self.ws, self._ws_key = ws, (N, B)
         return ws
 
+    def _c(self, name, *args):
+        if self.timing is None:
+            return call(name, *args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        call(name, *args)
+        b.record()
+        self._seq[name] = self._seq.get(name, 0) + 1
+        self.timing.setdefault("%s#%d" % (name, self._seq[name]), []).append((a, b))
+
+    def timing_summary(self):
+        """-> {call label: (n_launch_groups, mean ms)} from the recorded HIP events (synchronises)."""
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in (self.timing or {}).items()}
+
     # ------------------------------------------------------------------ forward
     def forward(self, pos, polarity, batch, num_graphs, image_feats, feats_are_nhwc=False):
         """pos f32[N,3] normalised (format_data output), polarity f32[N] or [N,1], batch i64[N],
         image_feats: the five CNN feature maps ([B,C,h,w], or [B,h,w,C] if feats_are_nhwc).
         Returns a dict with out3/out4 node arrays (padded) and their device-side counts."""
         g, st = self.geom, _stream()
+        self._seq = {}
         N, B = int(pos.shape[0]), int(num_graphs)
         ws = self._alloc(N, B)
         pos = pos.contiguous().float()
@@ -122,20 +139,20 @@ class NativeBackbone:
                 maps.append(m)
             else:
                 o = torch.empty((m.shape[0], m.shape[2], m.shape[3], m.shape[1]), dtype=torch.float32, device=m.device)
-                call("eventad_nchw_to_nhwc", ptr(m), ptr(o), m.shape[0], m.shape[1], m.shape[2], m.shape[3], st)
+                self._c("eventad_nchw_to_nhwc", ptr(m), ptr(o), m.shape[0], m.shape[1], m.shape[2], m.shape[3], st)
                 maps.append(o)
         assert [m.shape[3] for m in maps] == FEATURE_CHANNELS and all(m.shape[0] == B for m in maps)
         ws["counters"].zero_()
         w, K = self.w, g.max_neighbors
-        call("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
+        self._c("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
              N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
              ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["long_list"]), ptr(ws["counters"]),
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), st)
-        call("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
+        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), st)
-        call("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
+        self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
              ptr(w["root1"]), ptr(w["bn1"][0]), ptr(w["bn1"][1]), ptr(ws["y1"]), N, g.steps, K, st)
-        call("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
+        self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(w["lut2"]), ptr(w["root2"]), ptr(w["bn2"][0]), ptr(w["bn2"][1]), ptr(w["wskip"]), ptr(w["bns"][0]),
              ptr(w["bns"][1]), ptr(ws["y2"]), N, g.steps, K, st)
         levels = ws["levels"]
@@ -146,42 +163,42 @@ class NativeBackbone:
             mean = 1 if g.pool_aggr[lv] == "mean" else 0
             fmap = maps[lv + 1]
             if lv == 0:
-                call("eventad_pool_scatter", ptr(ws["y2"]), 16, 16, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
+                self._c("eventad_pool_scatter", ptr(ws["y2"]), 16, 16, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
                      ptr(ws["posn_s"]), None, None, ptr(ws["key_s"]), ptr(ws["sid"]), N, None, g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
                      ptr(ws["node_slot0"]), ptr(ws["counters"]), st)
                 boi = ws["bev"]
             else:
                 Lp = levels[lv - 1]
-                call("eventad_pool_scatter", ptr(Lp.y), 64, 64, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
+                self._c("eventad_pool_scatter", ptr(Lp.y), 64, 64, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
                      ptr(Lp.npos), ptr(Lp.npix), ptr(Lp.nbatch), None, None, Lp.n_max, ptr(Lp.n_dev), g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
                      ptr(Lp.node_slot_in), ptr(ws["counters"]), st)
                 boi = Lp.nbatch
-            call("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(boi),
+            self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(boi),
                  L.nx, L.ny, B, L.C, mean, 1 if lv == 0 else 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
                  ptr(ws["scan_tmp"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
                  ptr(L.slot2node), ptr(L.n_dev), st)
             if lv == 0:
-                call("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
+                self._c("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
                      L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
             else:
                 Lp = levels[lv - 1]
-                call("eventad_pool_edges_mark_csr", ptr(Lp.rowptr), ptr(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
+                self._c("eventad_pool_edges_mark_csr", ptr(Lp.rowptr), ptr(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
                      ptr(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
-            call("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
+            self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
                  ptr(L.n_dev), L.nx, L.ny, ptr(L.rowptr), ptr(ws["scan_tmp"]), ptr(L.csr_src), ptr(L.csr_dxy),
                  ptr(L.e_dev), st)
             # Layer lv+2 on this level's graph
             t = self.tail[lv]
             dvx, dvy = g.lut_div[lv + 1]
-            call("eventad_gemm_f32", ptr(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, ptr(L.n_dev),
+            self._c("eventad_gemm_f32", ptr(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, ptr(L.n_dev),
                  27 * 64, t["cin_pad"], None, None, None, None, 0, 0, st)
-            call("eventad_tail_blend", ptr(L.z1), 27 * 64, 25, None, 0, 0, ptr(L.rowptr), ptr(L.csr_src), ptr(L.csr_dxy),
+            self._c("eventad_tail_blend", ptr(L.z1), 27 * 64, 25, None, 0, 0, ptr(L.rowptr), ptr(L.csr_src), ptr(L.csr_dxy),
                  L.n_max, ptr(L.n_dev), dvx, dvy, ptr(t["bn1"][0]), ptr(t["bn1"][1]), None, None, ptr(L.y1), 64, st)
-            call("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, ptr(L.n_dev),
+            self._c("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, ptr(L.n_dev),
                  26 * 64, 64, None, None, None, None, 0, 0, st)
-            call("eventad_tail_blend", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, ptr(L.rowptr), ptr(L.csr_src),
+            self._c("eventad_tail_blend", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, ptr(L.rowptr), ptr(L.csr_src),
                  ptr(L.csr_dxy), L.n_max, ptr(L.n_dev), dvx, dvy, ptr(t["bn2"][0]), ptr(t["bn2"][1]), ptr(t["bns"][0]),
                  ptr(t["bns"][1]), ptr(L.y), 64, st)
             if lv == 2:

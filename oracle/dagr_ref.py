@@ -119,8 +119,11 @@ def init_lut(weight, height, width, rx, Mx, ry=None, My=None):
     dxy[1] = dxy[1] / (2 * My * height) + 0.5
     edge_attr = dxy.view((2, -1)).t()
     bil_w, indices = spline_basis(edge_attr)
-    lut = (bil_w[..., None, None] * weight[indices]).sum(1)
-    _, cin, cout = lut.shape
+    _, cin, cout = weight.shape
+    lut = torch.empty((edge_attr.shape[0], cin, cout), dtype=weight.dtype)
+    for s0 in range(0, edge_attr.shape[0], 2048):       # chunked: the layer-5 LUT is 1 GB at 256x256
+        e = slice(s0, s0 + 2048)
+        lut[e] = (bil_w[e][..., None, None] * weight[indices[e]]).sum(1)
     return lut.view((2 * rx + 1, 2 * ry + 1, cin, cout)), remap
 
 
@@ -132,7 +135,7 @@ def lut_indices(edge_attr, remap):
 
 
 def spline_conv(x, edge_index, edge_attr, weight, root_weight, lut_params, height, width,
-                mode="gather", chunk=1 << 18):
+                mode="gather", chunk=1 << 18, cached=None):
     """MySplineConv.forward/_forward with the cached LUT message
     (spline_conv.py:39-78), aggr='sum', root_weight=True, bias=None.
 
@@ -146,7 +149,7 @@ def spline_conv(x, edge_index, edge_attr, weight, root_weight, lut_params, heigh
     out = torch.zeros((n, cout), dtype=x.dtype)
     E = edge_index.shape[1]
     if E > 0:
-        lut, remap = init_lut(weight, height, width, rx=rx, Mx=M, ry=ry)
+        lut, remap = cached if cached is not None else init_lut(weight, height, width, rx=rx, Mx=M, ry=ry)
         dx, dy = lut_indices(edge_attr[:, :2], remap)
         assert int(dx.min()) >= 0 and int(dx.max()) <= 2 * rx, "LUT x index out of range"
         assert int(dy.min()) >= 0 and int(dy.max()) <= 2 * ry, "LUT y index out of range"
@@ -179,15 +182,28 @@ def batch_norm_eval(x, sd, prefix):
 
 
 # ------------------------------------------------------------------------- A14
-def layer(sd, prefix, x, edge_index, edge_attr, lut_params, height, width, mode):
+def cache_luts(sd, cfg, prefix="backbone."):
+    """DAGR.cache_luts (dagr.py:36-63): the ten backbone LUTs, built once at model set-up."""
+    luts = {}
+    for li, name in enumerate(["conv_block1.", "layer2.", "layer3.", "layer4.", "layer5."]):
+        rx, ry, M = cfg.lut[li]
+        for blk in ("conv_block1.", "conv_block2."):
+            k = prefix + name + blk + "conv.weight"
+            luts[k] = init_lut(sd[k], cfg.height, cfg.width, rx=rx, Mx=M, ry=ry)
+    return luts
+
+
+def layer(sd, prefix, x, edge_index, edge_attr, lut_params, height, width, mode, luts=None):
     """Layer = ConvBlock + ConvBlockWithSkip, src/dagr/model/layers/conv.py:10-72."""
     p1, p2 = prefix + "conv_block1.", prefix + "conv_block2."
     x_skip = x.clone()                                              # shallow_copy, utils.py:158-166
+    c1 = luts.get(p1 + "conv.weight") if luts else None
+    c2 = luts.get(p2 + "conv.weight") if luts else None
     y = spline_conv(x, edge_index, edge_attr, sd[p1 + "conv.weight"], sd[p1 + "conv.lin.weight"],
-                    lut_params, height, width, mode)
+                    lut_params, height, width, mode, cached=c1)
     y = F.relu(batch_norm_eval(y, sd, p1 + "norm.module."))         # conv.py:23-28
     z = spline_conv(y, edge_index, edge_attr, sd[p2 + "conv.weight"], sd[p2 + "conv.lin.weight"],
-                    lut_params, height, width, mode)
+                    lut_params, height, width, mode, cached=c2)
     s = x_skip @ sd[p2 + "lin.mlp.weight"].t()                      # conv.py:50
     s = batch_norm_eval(s, sd, p2 + "norm_skip.module.")
     z = batch_norm_eval(z, sd, p2 + "norm.module.")
@@ -276,7 +292,7 @@ def pooling(x, pos, batch, edge_index, voxel_size, cart_max, aggr, width, height
 
 
 # ------------------------------------------------------------------- A7 (+A10)
-def backbone_forward(sd, data, cfg, image_feats, mode="gather", prefix="backbone.", return_all=False):
+def backbone_forward(sd, data, cfg, image_feats, mode="gather", prefix="backbone.", return_all=False, luts=None):
     """Net.forward, src/dagr/model/networks/net.py:106-197 with use_image=True, num_scales=2.
     `data` is a formatted batch (A1).  `image_feats` = the five HookModule feature maps
     (A8; computed by oracle/resnet_ref.py or supplied as 'precomputed CNN features')."""
@@ -292,7 +308,7 @@ def backbone_forward(sd, data, cfg, image_feats, mode="gather", prefix="backbone
     names = ["conv_block1.", "layer2.", "layer3.", "layer4.", "layer5."]
     out3 = None
     for li in range(5):
-        x = layer(sd, prefix + names[li], x, edge_index, edge_attr, cfg.lut[li], H, W, mode)
+        x = layer(sd, prefix + names[li], x, edge_index, edge_attr, cfg.lut[li], H, W, mode, luts)
         stages["layer%d" % (li + 1)] = SimpleNamespace(x=x, pos=pos, batch=batch, edge_index=edge_index)
         if li == 3:
             out3 = SimpleNamespace(x=x.clone(), pos=pos, batch=batch, edge_index=edge_index, edge_attr=edge_attr)
