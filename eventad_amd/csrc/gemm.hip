@@ -1,121 +1,251 @@
-// eventad_amd/csrc/gemm.hip -- exact-fp32 MFMA GEMM for the dense parts of the path
-// (tail spline convolutions as X.[W_0|..|W_24|W_root|W_skip], 1x1 reducers, head projections).
+// eventad_amd/csrc/gemm.hip -- exact-fp32 MFMA GEMMs for the dense parts of the path
+// (tail spline convolutions as X.[W_0|..|W_24|W_root|W_skip], head GRU / fusion projections and
+// their weight gradients).
 //
-//   C[M,N] = epilogue( A[M,K] . B[K,N] )        all row-major fp32
+//   C[M,N] (+)= epilogue( op(A)[M,K] . op(B)[K,N] )        fp32, row-major storage
+//       op(A) = A        (A stored [M,K], lda)   or  A^T  (A stored [K,M], lda)      -- trans_a
+//       op(B) = B        (B stored [K,N], ldb)   or  B^T  (B stored [N,K], ldb)      -- trans_b
 //
 // v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: bitwise an fmaf chain in k order, so parity with
-// the fp32 CPU oracle is at rounding level).  128x128 block tile, 4 waves (2x2), each wave a
-// 64x64 sub-tile = 2x2 MFMA tiles; K is staged through LDS in slabs of 16, stored k-major so that
-// the operand read of lane l -- A[m0 + (l&31)][k0 + (l>>5)] -- is a conflict-free ds_read_b32.
+// the fp32 CPU oracle is at rounding level).  K is staged through LDS in slabs, stored k-major so
+// that the operand read of lane l -- A[m0 + (l&31)][k0 + (l>>5)] -- is a conflict-free ds_read_b32.
+//   k_gemm_f32<TM,TN>   4 waves (2x2), each wave TMxTN MFMA tiles: 128x128 block (TM=TN=2, big M)
+//                       or 64x64 block (TM=TN=1, the head's 256-row GEMMs)
+//   k_gemm_m32          M <= 32 rows (one clip step of the head): 32x64 block, the 4 waves split K
+//                       and reduce through LDS, so a [32,256]x[256,768] product is ~2 us of MFMA.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define GBM 128
-#define GBN 128
 #define GBK 16
 
-// epilogue: v = acc (+ bias[n]); v = v*scale[n] + shift[n] (if scale); v += residual[m,n] (if residual); relu
+// epilogue: v = acc (+ bias[n]); v = v*scale[n] + shift[n] (if scale); v += residual[m,n] (if residual);
+//           relu; C = accumulate ? C + v : v
 struct GemmEpi {
-    const float* bias; const float* scale; const float* shift; const float* residual; int ldr; int relu;
+    const float* bias; const float* scale; const float* shift; const float* residual; int ldr; int relu; int accumulate;
 };
 
+__device__ __forceinline__ float4 ld4_guard(const float* p, int i, int n) {
+    // p points at element i of a row with n valid elements
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i + 3 < n) v = *(const float4*)p;
+    else { if (i < n) v.x = p[0]; if (i + 1 < n) v.y = p[1]; if (i + 2 < n) v.z = p[2]; }
+    return v;
+}
+
+__device__ __forceinline__ float epilogue(float v, int gm, int gn, const GemmEpi& e, const float* C, int ldc) {
+    if (e.bias) v += e.bias[gn];
+    if (e.scale) v = fmaf(v, e.scale[gn], e.shift[gn]);
+    if (e.residual) v += e.residual[(size_t)gm * e.ldr + gn];
+    if (e.relu) v = fmaxf(v, 0.f);
+    if (e.accumulate) v += C[(size_t)gm * ldc + gn];
+    return v;
+}
+
+template <int TM, int TN, bool AT, bool BT>
 __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
                                                   float* __restrict__ C, int ldc, int M, const int* __restrict__ m_dev,
                                                   int N, int K, GemmEpi epi) {
-    __shared__ float As[GBK][GBM + 4];
-    __shared__ float Bs[GBK][GBN + 4];
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ float As[GBK][BM + 4];
+    __shared__ float Bs[GBK][BN + 4];
     if (m_dev) M = min(M, *m_dev);
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int k0 = 0; k0 < K; k0 += GBK) {
-        // A slab: 128 rows x 16 k  -> 512 float4 (4 k-values of one row), 2 per thread, stored transposed
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int f = tid + t * 256;
-            int row = f >> 2, kq = (f & 3) * 4;
-            int gm = m0 + row, gk = k0 + kq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < M) {
-                const float* p = A + (size_t)gm * lda + gk;
-                if (gk + 3 < K) v = *(const float4*)p;
-                else { if (gk < K) v.x = p[0]; if (gk + 1 < K) v.y = p[1]; if (gk + 2 < K) v.z = p[2]; }
+        // ---- A slab -> As[k][m]
+        if (!AT) {       // stored [M,K]: float4 along k, transposed store
+            for (int f = tid; f < BM * (GBK / 4); f += 256) {
+                int row = f >> 2, kq = (f & 3) * 4;
+                int gm = m0 + row, gk = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gm < M) v = ld4_guard(A + (size_t)gm * lda + gk, gk, K);
+                As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
             }
-            As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
+        } else {         // stored [K,M]: float4 along m, direct store
+            for (int f = tid; f < GBK * (BM / 4); f += 256) {
+                int kr = f / (BM / 4), mq = (f % (BM / 4)) * 4;
+                int gk = k0 + kr, gm = m0 + mq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < K) v = ld4_guard(A + (size_t)gk * lda + gm, gm, M);
+                *(float4*)&As[kr][mq] = v;
+            }
         }
-        // B slab: 16 k x 128 cols -> 512 float4 along n
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int f = tid + t * 256;
-            int kr = f >> 5, nq = (f & 31) * 4;
-            int gk = k0 + kr, gn = n0 + nq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < K) {
-                const float* p = Bm + (size_t)gk * ldb + gn;
-                if (gn + 3 < N) v = *(const float4*)p;
-                else { if (gn < N) v.x = p[0]; if (gn + 1 < N) v.y = p[1]; if (gn + 2 < N) v.z = p[2]; }
+        // ---- B slab -> Bs[k][n]
+        if (!BT) {       // stored [K,N]: float4 along n
+            for (int f = tid; f < GBK * (BN / 4); f += 256) {
+                int kr = f / (BN / 4), nq = (f % (BN / 4)) * 4;
+                int gk = k0 + kr, gn = n0 + nq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < K) v = ld4_guard(Bm + (size_t)gk * ldb + gn, gn, N);
+                *(float4*)&Bs[kr][nq] = v;
             }
-            *(float4*)&Bs[kr][nq] = v;
+        } else {         // stored [N,K]: float4 along k, transposed store
+            for (int f = tid; f < BN * (GBK / 4); f += 256) {
+                int col = f >> 2, kq = (f & 3) * 4;
+                int gn = n0 + col, gk = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gn < N) v = ld4_guard(Bm + (size_t)gn * ldb + gk, gk, K);
+                Bs[kq][col] = v.x; Bs[kq + 1][col] = v.y; Bs[kq + 2][col] = v.z; Bs[kq + 3][col] = v.w;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
             int kr = kk + (lane >> 5), c = lane & 31;
-            float a0 = As[kr][wm + c], a1 = As[kr][wm + 32 + c];
-            float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 32 + c];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[kr][wm + 32 * i + c];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kr][wn + 32 * j + c];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
     // C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
             int gn = n0 + wn + j * 32 + (lane & 31);
             if (gn >= N) continue;
-            float bia = epi.bias ? epi.bias[gn] : 0.f;
-            float sc = epi.scale ? epi.scale[gn] : 1.f, sh = epi.scale ? epi.shift[gn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int gm = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (gm >= M) continue;
-                float v = acc[i][j][r] + bia;
-                if (epi.scale) v = fmaf(v, sc, sh);
-                if (epi.residual) v += epi.residual[(size_t)gm * epi.ldr + gn];
-                if (epi.relu) v = fmaxf(v, 0.f);
-                C[(size_t)gm * ldc + gn] = v;
+                C[(size_t)gm * ldc + gn] = epilogue(acc[i][j][r], gm, gn, epi, C, ldc);
             }
         }
 }
 
-int evad_gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, const int* m_dev, int N, int K,
-              GemmEpi epi, hipStream_t st) {
+// ---- M <= 32: one 32x64 output block per workgroup, K split over the 4 waves inside each slab
+#define SBK 32
+template <bool BT>
+__global__ __launch_bounds__(256) void k_gemm_m32(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                  float* __restrict__ C, int ldc, int M, int N, int K, GemmEpi epi) {
+    __shared__ float As[SBK][32 + 1];
+    __shared__ float Bs[SBK][64 + 4];
+    __shared__ float Red[3][32][64 + 1];
+    const int n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += SBK) {
+        {   // A slab: 32 rows x 32 k = 256 float4
+            int row = tid >> 3, kq = (tid & 7) * 4, gk = k0 + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) v = ld4_guard(A + (size_t)row * lda + gk, gk, K);
+            As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
+        }
+        if (!BT) {
+            for (int f = tid; f < SBK * 16; f += 256) {
+                int kr = f >> 4, nq = (f & 15) * 4, gk = k0 + kr, gn = n0 + nq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < K) v = ld4_guard(Bm + (size_t)gk * ldb + gn, gn, N);
+                *(float4*)&Bs[kr][nq] = v;
+            }
+        } else {
+            for (int f = tid; f < 64 * (SBK / 4); f += 256) {
+                int col = f >> 3, kq = (f & 7) * 4, gn = n0 + col, gk = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gn < N) v = ld4_guard(Bm + (size_t)gn * ldb + gk, gk, K);
+                Bs[kq][col] = v.x; Bs[kq + 1][col] = v.y; Bs[kq + 2][col] = v.z; Bs[kq + 3][col] = v.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < SBK / 4; kk += 2) {                   // this wave's quarter of the slab
+            int kr = wave * (SBK / 4) + kk + (lane >> 5), c = lane & 31;
+            float a = As[kr][c];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[kr][c], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[kr][32 + c], acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Red[wave - 1][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][j * 32 + (lane & 31)] = acc[j][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int col = j * 32 + (lane & 31), gn = n0 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int gm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gn >= N || gm >= M) continue;
+                float v = ((acc[j][r] + Red[0][gm][col]) + Red[1][gm][col]) + Red[2][gm][col];
+                C[(size_t)gm * ldc + gn] = epilogue(v, gm, gn, epi, C, ldc);
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+static void launch_big(bool ta, bool tb, dim3 grid, hipStream_t st, const float* A, int lda, const float* Bm, int ldb,
+                       float* C, int ldc, int M, const int* m_dev, int N, int K, GemmEpi epi) {
+    if (!ta && !tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, false, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+    else if (!ta && tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, false, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+    else if (ta && !tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, true, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+    else hipLaunchKernelGGL((k_gemm_f32<TM, TN, true, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+}
+
+int evad_gemm(bool ta, bool tb, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M,
+              const int* m_dev, int N, int K, GemmEpi epi, hipStream_t st) {
     if (M <= 0 || N <= 0) return EVAD_OK;
-    dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM);
-    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+    if (M <= 32 && !ta && !m_dev) {
+        dim3 grid((N + 63) / 64);
+        if (tb) hipLaunchKernelGGL(k_gemm_m32<true>, grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, N, K, epi);
+        else    hipLaunchKernelGGL(k_gemm_m32<false>, grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, N, K, epi);
+    } else if ((long long)M * N >= 128ll * 128 * 256) {
+        launch_big<2, 2>(ta, tb, dim3((N + 127) / 128, (M + 127) / 128), st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+    } else {
+        launch_big<1, 1>(ta, tb, dim3((N + 63) / 64, (M + 63) / 64), st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+    }
     return evad_last_error();
 }
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int eventad_gemm_f32(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M,
                                 const int32_t* m_dev, int N, int K, const float* bias, const float* scale,
                                 const float* shift, const float* residual, int ldr, int relu, void* stream) {
     if (!A || !Bm || !C || M < 0 || N < 0 || K < 0 || lda < K || ldb < N || ldc < N || (lda & 3) || (ldb & 3) ||
-        ((uintptr_t)A & 15) || ((uintptr_t)Bm & 15) || (scale && !shift))
+        !al16(A) || !al16(Bm) || (scale && !shift))
         return EVAD_ERR_ARG;
-    GemmEpi epi{bias, scale, shift, residual, ldr, relu};
-    return evad_gemm(A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi, (hipStream_t)stream);
+    GemmEpi epi{bias, scale, shift, residual, ldr, relu, 0};
+    return evad_gemm(false, false, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi, (hipStream_t)stream);
+}
+
+/* General form: trans_a / trans_b select the stored layout of A / B (see file header);
+ * accumulate != 0 adds into C.  Leading dimensions must be multiples of 4 and bases 16-byte aligned. */
+extern "C" int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int lda, const float* Bm, int ldb, float* C,
+                                   int ldc, int M, int N, int K, const float* bias, int relu, int accumulate,
+                                   void* stream) {
+    if (!A || !Bm || !C || M < 0 || N < 0 || K < 0 || (lda & 3) || (ldb & 3) || !al16(A) || !al16(Bm) || ldc < N ||
+        lda < (trans_a ? M : K) || ldb < (trans_b ? K : N))
+        return EVAD_ERR_ARG;
+    GemmEpi epi{bias, nullptr, nullptr, nullptr, 0, relu, accumulate};
+    return evad_gemm(trans_a != 0, trans_b != 0, A, lda, Bm, ldb, C, ldc, M, nullptr, N, K, epi, (hipStream_t)stream);
 }

@@ -1,0 +1,346 @@
+// eventad_amd/csrc/head.hip -- the EventAD anomaly head (forward + backward) and its optimiser.
+//
+// Reference: EventADModel.forward (models/EventAD.py:178-333) -- for every clip of the batch, for
+// every track id 1..30: GRU(64->256, 2 layers) on the ROI feature, GRU(4->32) on the box, fusion MLP,
+// cross-entropy; hidden states handed from clip to clip through a soft attention over the tracks of
+// the clip (:320-323).  Reference cost: B*30 Python iterations with >=3 host syncs each and M=1 GEMVs.
+//
+// Native formulation: 32 track slots per clip (slot 0 and 31 never valid), a device-side validity
+// mask instead of Python `continue`s, [32,H] state arrays instead of dicts.  Everything that does not
+// depend on the clip-to-clip chain is batched over all B*32 rows (input projections, fusion MLP, all
+// weight gradients -> gemm.hip); the chain itself is 4 small launches per clip forward and 5 backward.
+// The kernels here are the element-wise / reduction pieces between the GEMMs.
+#include "common.h"
+
+#define NT 32          // track slots per clip
+#define FEAT_T 31      // rows of the ROI feature table per (clip, frame)  (reference: max_boxes + 1)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// (clip, track) lookup tables: replaces EventAD.py:229-255 (first matching box row, normalised box,
+// label) and gathers the current-frame ROI features into the GEMM operand X[B*32, 64].
+__global__ void k_head_tables(const float* __restrict__ bbox, const long long* __restrict__ bbox_batch, int M,
+                              const float* __restrict__ labels, const float* __restrict__ feats, int B, float Wimg,
+                              float Himg, float* __restrict__ X, float* __restrict__ CO, int* __restrict__ target,
+                              int* __restrict__ valid) {
+    int row = blockIdx.x, b = row / NT, k = row % NT, j = threadIdx.x;      // 64 threads = 64 channels
+    float f = 0.f;
+    if (k >= 1 && k < FEAT_T) f = feats[(((size_t)b * 2 + 1) * FEAT_T + k) * 64 + j];
+    X[(size_t)row * 64 + j] = f;
+    float s = f;                                                            // torch.sum(curr_feature) == 0 ?
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (j == 0) {
+        int found = -1;
+        if (k >= 1 && k < FEAT_T)
+            for (int m = 0; m < M; ++m)
+                if ((int)bbox_batch[m] == b && bbox[(size_t)m * 6 + 5] == (float)k) { found = m; break; }
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f; int t = 0;
+        if (found >= 0) {
+            const float* bb = bbox + (size_t)found * 6;
+            c0 = (float)((double)bb[0] / (double)Wimg); c1 = (float)((double)bb[1] / (double)Himg);
+            c2 = (float)((double)bb[2] / (double)Wimg); c3 = (float)((double)bb[3] / (double)Himg);
+            t = labels ? (int)labels[found] : 0;
+        }
+        CO[(size_t)row * 4] = c0; CO[(size_t)row * 4 + 1] = c1; CO[(size_t)row * 4 + 2] = c2; CO[(size_t)row * 4 + 3] = c3;
+        target[row] = t;
+        valid[row] = (found >= 0 && s != 0.f) ? 1 : 0;
+    }
+}
+
+extern "C" int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, const float* labels,
+                                   const float* feats, int B, int width, int height, float* X, float* CO,
+                                   int32_t* target, int32_t* valid, void* stream) {
+    if (!feats || !X || !CO || !target || !valid || B <= 0 || M < 0 || (M > 0 && (!bbox || !bbox_batch))) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_head_tables, dim3(B * NT), dim3(64), 0, (hipStream_t)stream, bbox, (const long long*)bbox_batch, M,
+                       labels, feats, B, (float)width, (float)height, X, CO, target, valid);
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRU cell (PyTorch gate order r,z,n): h' = (1-z)*n + z*h,  n = tanh(gi_n + r*gh_n).
+// gates_out keeps (r,z,n) for the backward pass; xdrop = h' * mask is the dropout'd input of the
+// next GRU layer (nn.GRU(dropout=0.3), EventAD.py:86).
+__global__ void k_gru_cell_fwd(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hprev,
+                               int rows, int H, float* __restrict__ gates, float* __restrict__ hnew,
+                               const float* __restrict__ mask, float* __restrict__ xdrop) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * H) return;
+    int row = t / H, j = t % H;
+    const float* a = gi + (size_t)row * 3 * H; const float* c = gh + (size_t)row * 3 * H;
+    float r = sigmoidf_(a[j] + c[j]);
+    float z = sigmoidf_(a[H + j] + c[H + j]);
+    float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    float h = hprev[t];
+    float hn = (1.f - z) * n + z * h;
+    float* g = gates + (size_t)row * 3 * H;
+    g[j] = r; g[H + j] = z; g[2 * H + j] = n;
+    hnew[t] = hn;
+    if (xdrop) xdrop[t] = mask ? hn * mask[t] : hn;
+}
+
+extern "C" int eventad_gru_cell_fwd(const float* gi, const float* gh, const float* hprev, int rows, int H, float* gates,
+                                    float* hnew, const float* mask, float* xdrop, void* stream) {
+    if (!gi || !gh || !hprev || !gates || !hnew || rows <= 0 || H <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_gru_cell_fwd, dim3(evad_blocks((long long)rows * H, 256)), dim3(256), 0, (hipStream_t)stream, gi, gh,
+                       hprev, rows, H, gates, hnew, mask, xdrop);
+    return evad_last_error();
+}
+
+// dh = dHn (+ dx_extra*mask);  dn = dh*(1-z), dz = dh*(h-n), dh_prev = dSpass + dh*z;
+// dgi = (da_r, da_z, da_n), dgh = (da_r, da_z, da_n*r)  with da_n = dn*(1-n^2), da_z = dz*z(1-z),
+// da_r = da_n*gh_n*r(1-r).
+__global__ void k_gru_cell_bwd(const float* __restrict__ dhn, const float* __restrict__ dx_extra,
+                               const float* __restrict__ mask, const float* __restrict__ gates, const float* __restrict__ gh,
+                               const float* __restrict__ hprev, const float* __restrict__ dspass, int rows, int H,
+                               float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dsprev) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * H) return;
+    int row = t / H, j = t % H;
+    float dh = dhn[t];
+    if (dx_extra) dh += mask ? dx_extra[t] * mask[t] : dx_extra[t];
+    const float* g = gates + (size_t)row * 3 * H;
+    float r = g[j], z = g[H + j], n = g[2 * H + j];
+    float ghn = gh[(size_t)row * 3 * H + 2 * H + j];
+    float h = hprev[t];
+    float dn = dh * (1.f - z), dz = dh * (h - n);
+    float dan = dn * (1.f - n * n);
+    float daz = dz * z * (1.f - z);
+    float dar = dan * ghn * r * (1.f - r);
+    float* a = dgi + (size_t)row * 3 * H; float* c = dgh + (size_t)row * 3 * H;
+    a[j] = dar; a[H + j] = daz; a[2 * H + j] = dan;
+    c[j] = dar; c[H + j] = daz; c[2 * H + j] = dan * r;
+    dsprev[t] = dspass[t] + dh * z;
+}
+
+extern "C" int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* mask, const float* gates,
+                                    const float* gh, const float* hprev, const float* dspass, int rows, int H,
+                                    float* dgi, float* dgh, float* dsprev, void* stream) {
+    if (!dhn || !gates || !gh || !hprev || !dspass || !dgi || !dgh || !dsprev || rows <= 0 || H <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_gru_cell_bwd, dim3(evad_blocks((long long)rows * H, 256)), dim3(256), 0, (hipStream_t)stream, dhn,
+                       dx_extra, mask, gates, gh, hprev, dspass, rows, H, dgi, dgh, dsprev);
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpatialAttention (EventAD.py:100-138) over the valid tracks of one clip, one block per call:
+//   s_k = tanh(Hn_k).w ; alpha = softmax_valid(s) ; S'_k = valid ? Hn_k*alpha_k : S_k (state kept)
+__global__ __launch_bounds__(256) void k_att_fwd(const float* __restrict__ Hn, const float* __restrict__ Sprev,
+                                                 const int* __restrict__ valid, const float* __restrict__ w, int H,
+                                                 float* __restrict__ alpha, float* __restrict__ Snext) {
+    __shared__ float s_s[NT], s_a[NT];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < NT; k += 4) {
+        float acc = 0.f;
+        for (int j = lane; j < H; j += 64) acc += tanhf(Hn[(size_t)k * H + j]) * w[j];
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+        if (lane == 0) s_s[k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = -3.4e38f; int any = 0;
+        for (int k = 0; k < NT; ++k) if (valid[k]) { m = fmaxf(m, s_s[k]); any = 1; }
+        float sum = 0.f;
+        for (int k = 0; k < NT; ++k) { float e = (any && valid[k]) ? expf(s_s[k] - m) : 0.f; s_a[k] = e; sum += e; }
+        for (int k = 0; k < NT; ++k) { float a = any && valid[k] ? s_a[k] / sum : 0.f; s_a[k] = a; alpha[k] = a; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NT * H; t += 256) {
+        int k = t / H;
+        Snext[t] = valid[k] ? Hn[t] * s_a[k] : Sprev[t];
+    }
+}
+
+extern "C" int eventad_att_fwd(const float* Hn, const float* Sprev, const int32_t* valid, const float* w, int H,
+                               float* alpha, float* Snext, void* stream) {
+    if (!Hn || !Sprev || !valid || !w || !alpha || !Snext || H <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_att_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, Hn, Sprev, valid, w, H, alpha, Snext);
+    return evad_last_error();
+}
+
+// backward of the above: dHn (total, incl. dHn_out from the fusion branch), dSpass (rows whose state
+// was kept), dw += this clip's contribution (deterministic: one thread per j sums the tracks in order).
+__global__ __launch_bounds__(256) void k_att_bwd(const float* __restrict__ dSnext, const float* __restrict__ dHn_out,
+                                                 const float* __restrict__ Hn, const float* __restrict__ alpha,
+                                                 const int* __restrict__ valid, const float* __restrict__ w, int H,
+                                                 float* __restrict__ dHn, float* __restrict__ dSpass, float* __restrict__ dw) {
+    __shared__ float s_da[NT], s_ds[NT];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < NT; k += 4) {
+        float acc = 0.f;
+        if (valid[k]) for (int j = lane; j < H; j += 64) acc += dSnext[(size_t)k * H + j] * Hn[(size_t)k * H + j];
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+        if (lane == 0) s_da[k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float dot = 0.f;
+        for (int k = 0; k < NT; ++k) if (valid[k]) dot += alpha[k] * s_da[k];
+        for (int k = 0; k < NT; ++k) s_ds[k] = valid[k] ? alpha[k] * (s_da[k] - dot) : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NT * H; t += 256) {
+        int k = t / H, j = t % H;
+        float g = dSnext[t];
+        if (valid[k]) {
+            float th = tanhf(Hn[t]);
+            float d = g * alpha[k] + s_ds[k] * w[j] * (1.f - th * th);
+            if (dHn_out) d += dHn_out[t];
+            dHn[t] = d; dSpass[t] = 0.f;
+        } else { dHn[t] = 0.f; dSpass[t] = g; }
+    }
+    for (int j = threadIdx.x; j < H; j += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < NT; ++k) if (valid[k]) acc += s_ds[k] * tanhf(Hn[(size_t)k * H + j]);
+        dw[j] += acc;
+    }
+}
+
+extern "C" int eventad_att_bwd(const float* dSnext, const float* dHn_out, const float* Hn, const float* alpha,
+                               const int32_t* valid, const float* w, int H, float* dHn, float* dSpass, float* dw,
+                               void* stream) {
+    if (!dSnext || !Hn || !alpha || !valid || !w || !dHn || !dSpass || !dw || H <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_att_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dSnext, dHn_out, Hn, alpha, valid, w, H, dHn,
+                       dSpass, dw);
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output layer + cross-entropy (Fuse_GRUNet.fusion[3], EventAD.py:27,280-281): one wave per row.
+// F1r = ReLU(fusion.0(...)) [R,256]; D2 = dropout mask (nullable).  Writes logits, d(loss)/d(logits)
+// (masked by validity) and the per-row loss; k_loss_sum adds the rows in (clip, track) order, which
+// is the order of the reference's `losses['cross_entropy'] += loss`.
+__global__ void k_fuse_out(const float* __restrict__ F1r, const float* __restrict__ D2, const float* __restrict__ Wo,
+                           const float* __restrict__ bo, const int* __restrict__ target, const int* __restrict__ valid,
+                           int R, float* __restrict__ logits, float* __restrict__ dlog, float* __restrict__ loss_rows) {
+    int row = blockIdx.x, lane = threadIdx.x;
+    if (row >= R) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = lane; j < 256; j += 64) {
+        float f = F1r[(size_t)row * 256 + j];
+        if (D2) f *= D2[(size_t)row * 256 + j];
+        a0 += f * Wo[j]; a1 += f * Wo[256 + j];
+    }
+    for (int d = 32; d > 0; d >>= 1) { a0 += __shfl_down(a0, d, 64); a1 += __shfl_down(a1, d, 64); }
+    if (lane == 0) {
+        float l0 = a0 + bo[0], l1 = a1 + bo[1];
+        logits[2 * row] = l0; logits[2 * row + 1] = l1;
+        float m = fmaxf(l0, l1), e0 = expf(l0 - m), e1 = expf(l1 - m), s = e0 + e1;
+        int t = target[row], v = valid[row];
+        float lse = logf(s) + m;
+        loss_rows[row] = v ? lse - (t ? l1 : l0) : 0.f;
+        dlog[2 * row] = v ? e0 / s - (t == 0 ? 1.f : 0.f) : 0.f;
+        dlog[2 * row + 1] = v ? e1 / s - (t == 1 ? 1.f : 0.f) : 0.f;
+    }
+}
+
+__global__ void k_loss_sum(const float* __restrict__ loss_rows, int R, float* __restrict__ loss) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += loss_rows[r];
+        *loss = s;
+    }
+}
+
+extern "C" int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
+                                const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss,
+                                void* stream) {
+    if (!F1r || !Wo || !bo || !target || !valid || !logits || !dlog || !loss_rows || !loss || R <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_fuse_out, dim3(R), dim3(64), 0, (hipStream_t)stream, F1r, D2, Wo, bo, target, valid, R, logits, dlog, loss_rows);
+    hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_rows, R, loss);
+    return evad_last_error();
+}
+
+// backward of the output layer: dWo, dbo, and dPre[R,256] = (dlog.Wo) * D2 * [F1r > 0]
+__global__ void k_out_bwd(const float* __restrict__ dlog, const float* __restrict__ Wo, const float* __restrict__ F1r,
+                          const float* __restrict__ D2, int R, float* __restrict__ dPre, float* __restrict__ dWo,
+                          float* __restrict__ dbo) {
+    int j = threadIdx.x;                                    // 256 threads, one block
+    float w0 = Wo[j], w1 = Wo[256 + j], g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
+    for (int r = 0; r < R; ++r) {
+        float d0 = dlog[2 * r], d1 = dlog[2 * r + 1];
+        float fr = F1r[(size_t)r * 256 + j], m = D2 ? D2[(size_t)r * 256 + j] : 1.f;
+        float f = fr * m;
+        g0 += d0 * f; g1 += d1 * f; b0 += d0; b1 += d1;
+        dPre[(size_t)r * 256 + j] = fr > 0.f ? (d0 * w0 + d1 * w1) * m : 0.f;
+    }
+    dWo[j] = g0; dWo[256 + j] = g1;
+    if (j == 0) { dbo[0] = b0; dbo[1] = b1; }
+}
+
+extern "C" int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
+                               float* dWo, float* dbo, void* stream) {
+    if (!dlog || !Wo || !F1r || !dPre || !dWo || !dbo || R <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_out_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dlog, Wo, F1r, D2, R, dPre, dWo, dbo);
+    return evad_last_error();
+}
+
+// column sums (bias gradients): out[n] = sum_r A[r, n]
+__global__ void k_colsum(const float* __restrict__ A, int lda, int R, int N, float* __restrict__ out) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += A[(size_t)r * lda + n];
+    out[n] = s;
+}
+
+extern "C" int eventad_colsum(const float* A, int lda, int R, int N, float* out, void* stream) {
+    if (!A || !out || R <= 0 || N <= 0 || lda < N) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_colsum, dim3(evad_blocks(N, 64)), dim3(64), 0, (hipStream_t)stream, A, lda, R, N, out);
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Optimiser: clip_grad_norm_(max_norm) + AdamW on flat fp32 buffers (utils/train.py:27-53,141-152).
+//   state[0]=step  [1]=grad norm  [2]=clip coefficient  [3]=1-beta1^t  [4]=1-beta2^t  [5]=non-finite count
+#define NORM_BLOCKS 256
+__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, int n, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += NORM_BLOCKS * 256) s += g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void k_opt_prepare(const float* __restrict__ partial, float max_norm, double beta1, double beta2, float* __restrict__ state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = 0.f;
+    for (int i = 0; i < NORM_BLOCKS; ++i) s += partial[i];
+    float norm = sqrtf(s);
+    float step = state[0] + 1.f;
+    state[0] = step; state[1] = norm;
+    float coef = max_norm / (norm + 1e-6f);                 // torch.nn.utils.clip_grad_norm_
+    state[2] = coef < 1.f ? coef : 1.f;
+    state[3] = (float)(1.0 - pow(beta1, (double)step)); state[4] = (float)(1.0 - pow(beta2, (double)step));
+    if (!isfinite(norm)) state[5] += 1.f;
+}
+
+__global__ void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
+                        float lr, float beta1, float omb1, float beta2, float omb2, float eps, float decay,
+                        const float* __restrict__ state) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * state[2];
+    g[i] = gi;                                              // grads are left clipped, as clip_grad_norm_ does
+    float pi = p[i] * decay;
+    float mi = beta1 * m[i] + omb1 * gi;
+    float vi = beta2 * v[i] + omb2 * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) / sqrtf(state[4]) + eps;
+    p[i] = pi - (lr / state[3]) * (mi / denom);
+}
+
+extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr,
+                                  double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                                  float* partial, float* state, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !partial || !state || n <= 0) return EVAD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sqnorm_partial, dim3(NORM_BLOCKS), dim3(256), 0, st, grads, n, partial);
+    hipLaunchKernelGGL(k_opt_prepare, dim3(1), dim3(64), 0, st, partial, (float)max_norm, beta1, beta2, state);
+    hipLaunchKernelGGL(k_adamw, dim3(evad_blocks(n, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (float)lr,
+                       (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(1.0 - lr * weight_decay), state);
+    return evad_last_error();
+}

@@ -1,0 +1,223 @@
+"""Native (HIP) execution of the EventAD head: forward, backward and the clip+AdamW update
+(reference models/EventAD.py:178-333 and utils/train.py:100-152), driving csrc/head.hip + csrc/gemm.hip
+through the C ABI.  Host logic only: flat parameter / gradient / optimiser-state buffers (the model's
+nn.Parameters are re-bound as views into them, so state_dict()/load_state_dict() keep working and a
+data-parallel all-reduce is ONE collective on `flat_grads`), workspace, and the launch sequence.
+
+Row convention: R = B*32 rows, row = clip*32 + track slot (slots 0 and 31 are never valid)."""
+import ctypes
+
+import torch
+
+from ._lib import call, ptr
+
+NT = 32
+# used head parameters in flat-buffer order (fusion_module.attention.* never receives a gradient, EventAD.py:20)
+PARAMS = [
+    ("gru_net_event.gru.weight_ih_l0", (768, 64)), ("gru_net_event.gru.weight_hh_l0", (768, 256)),
+    ("gru_net_event.gru.bias_ih_l0", (768,)), ("gru_net_event.gru.bias_hh_l0", (768,)),
+    ("gru_net_event.gru.weight_ih_l1", (768, 256)), ("gru_net_event.gru.weight_hh_l1", (768, 256)),
+    ("gru_net_event.gru.bias_ih_l1", (768,)), ("gru_net_event.gru.bias_hh_l1", (768,)),
+    ("gru_net_cor.gru.weight_ih_l0", (96, 4)), ("gru_net_cor.gru.weight_hh_l0", (96, 32)),
+    ("gru_net_cor.gru.bias_ih_l0", (96,)), ("gru_net_cor.gru.bias_hh_l0", (96,)),
+    ("fusion_module.event_proj.weight", (256, 256)), ("fusion_module.event_proj.bias", (256,)),
+    ("fusion_module.coord_proj.weight", (256, 32)), ("fusion_module.coord_proj.bias", (256,)),
+    ("fusion_module.fusion.0.weight", (256, 512)), ("fusion_module.fusion.0.bias", (256,)),
+    ("fusion_module.fusion.3.weight", (2, 256)), ("fusion_module.fusion.3.bias", (2,)),
+    ("soft_attention.weight", (256, 1)), ("soft_attention_cor.weight", (32, 1)),
+]
+
+
+def _rp(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class NativeHead:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, grad_clip=1.0):
+        self.model = model
+        self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, grad_clip
+        params = dict(model.named_parameters())
+        dev = params[PARAMS[0][0]].device
+        assert dev.type == "cuda", "the native head needs the model on a GPU (no CPU path)"
+        self.dev = dev
+        self.off, off = {}, 0
+        for name, shape in PARAMS:
+            assert tuple(params[name].shape) == shape, name
+            self.off[name] = off
+            n = params[name].numel()
+            off += (n + 3) // 4 * 4                           # keep every tensor 16-byte aligned
+        self.n = off
+        self.flat = torch.zeros(off, device=dev)
+        self.grads = torch.zeros(off, device=dev)
+        self.exp_avg = torch.zeros(off, device=dev)
+        self.exp_avg_sq = torch.zeros(off, device=dev)
+        self.partial = torch.zeros(256, device=dev)
+        self.opt_state = torch.zeros(8, device=dev)
+        self.P, self.G = {}, {}
+        for name, shape in PARAMS:
+            p = params[name]
+            n, o = p.numel(), self.off[name]
+            v = self.flat[o:o + n].view(shape)
+            v.copy_(p.data)
+            p.data = v                                        # the module parameter IS the flat buffer slice
+            g = self.grads[o:o + n].view(shape)            # native-path gradients live here (not in p.grad:
+                                                           # autograd would add the bridge's result onto itself)
+            self.P[name], self.G[name] = v, g
+        self._B = None
+
+    def bound(self):
+        """True while the model's parameters still alias the flat buffer (a later .to()/.cuda() breaks it)."""
+        params = dict(self.model.named_parameters())
+        return all(params[n].data_ptr() == self.P[n].data_ptr() for n, _ in PARAMS)
+
+    # ---------------------------------------------------------------- workspace
+    def _alloc(self, B):
+        if self._B == B:
+            return
+        R, dev = B * NT, self.dev
+        f = lambda *s: torch.zeros(s, device=dev)
+        i = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)
+        w = self.w = {}
+        w["X"], w["CO"], w["target"], w["valid"] = f(R, 64), f(R, 4), i(R), i(R)
+        for k, n in (("GI0", 768), ("GH0", 768), ("G0", 768), ("GI1", 768), ("GH1", 768), ("G1", 768),
+                     ("GIC", 96), ("GHC", 96), ("GC", 96), ("dGI0", 768), ("dGH0", 768), ("dGI1", 768),
+                     ("dGH1", 768), ("dGIC", 96), ("dGHC", 96)):
+            w[k] = f(R, n)
+        for k, n in (("S0", 256), ("S1", 256), ("SC", 32)):
+            w[k] = f(R + NT, n)
+        for k, n in (("H0n", 256), ("X1", 256), ("H1n", 256), ("HCn", 32), ("F1r", 256), ("dPre", 256),
+                     ("dH1o", 256), ("dHCo", 32)):
+            w[k] = f(R, n)
+        w["ZCAT"], w["dZCAT"] = f(R, 512), f(R, 512)
+        w["AL0"], w["AL1"], w["ALC"] = f(R), f(R), f(R)
+        w["logits"], w["dlog"], w["loss_rows"], w["loss"] = f(R, 2), f(R, 2), f(R), f(1)
+        for k, n in (("dS0a", 256), ("dS0b", 256), ("dS1a", 256), ("dS1b", 256), ("dSCa", 32), ("dSCb", 32),
+                     ("dHn0", 256), ("dHn1", 256), ("dHnC", 32), ("dSp0", 256), ("dSp1", 256), ("dSpC", 32), ("dX1", 256)):
+            w[k] = f(NT, n)
+        self._B = B
+
+    @staticmethod
+    def _gemm(ta, tb, A, lda, Bm, ldb, C, ldc, M, N, K, bias=None, relu=0, acc=0):
+        call("eventad_gemm_f32_ex", ta, tb, _rp(A), lda, _rp(Bm), ldb, _rp(C), ldc, M, N, K, _rp(bias), relu, acc,
+             torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train):
+        """feats f32[B,2,31,64] (ROI features), bbox f32[M,6], bbox_batch i64[M], labels f32[M] or None.
+        Returns (loss 0-d, logits [B,32,2], valid bool[B,32], targets i64[B,32]); keeps what backward needs."""
+        self._alloc(B)
+        w, P, g = self.w, self.P, self._gemm
+        st = torch.cuda.current_stream().cuda_stream
+        R = B * NT
+        M = int(bbox.shape[0]) if bbox is not None else 0
+        bbox_c = bbox.contiguous().float() if M else None
+        bb_c = bbox_batch.contiguous().long() if M else None
+        lab_c = labels.contiguous().float() if (M and labels is not None) else None
+        call("eventad_head_tables", _rp(bbox_c), _rp(bb_c), M, _rp(lab_c), ptr(feats), B, int(width), int(height),
+             ptr(w["X"]), ptr(w["CO"]), ptr(w["target"]), ptr(w["valid"]), st)
+        self.D1 = self.D2 = None
+        if train:                                              # nn.GRU(dropout=.3) between layers; fusion Dropout(.3)
+            self.D1 = torch.bernoulli(torch.full((R, 256), 0.7, device=self.dev)) / 0.7
+            self.D2 = torch.bernoulli(torch.full((R, 256), 0.7, device=self.dev)) / 0.7
+        ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
+        g(0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, bias=P[ev + "bias_ih_l0"])
+        g(0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, bias=P[co + "bias_ih_l0"])
+        w["S0"][:NT].zero_(); w["S1"][:NT].zero_(); w["SC"][:NT].zero_()
+        for b in range(B):                                     # the clip-to-clip hidden-state chain (EventAD.py:211-323)
+            r0, r1 = b * NT, (b + 1) * NT
+            vb = w["valid"][r0:r1]
+            g(0, 1, w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, bias=P[ev + "bias_hh_l0"])
+            g(0, 1, w["S1"][r0:r1], 256, P[ev + "weight_hh_l1"], 256, w["GH1"][r0:r1], 768, NT, 768, 256, bias=P[ev + "bias_hh_l1"])
+            g(0, 1, w["SC"][r0:r1], 32, P[co + "weight_hh_l0"], 32, w["GHC"][r0:r1], 96, NT, 96, 32, bias=P[co + "bias_hh_l0"])
+            d1 = self.D1[r0:r1] if train else None
+            call("eventad_gru_cell_fwd", _rp(w["GI0"][r0:r1]), _rp(w["GH0"][r0:r1]), _rp(w["S0"][r0:r1]), NT, 256,
+                 _rp(w["G0"][r0:r1]), _rp(w["H0n"][r0:r1]), _rp(d1), _rp(w["X1"][r0:r1]), st)
+            g(0, 1, w["X1"][r0:r1], 256, P[ev + "weight_ih_l1"], 256, w["GI1"][r0:r1], 768, NT, 768, 256, bias=P[ev + "bias_ih_l1"])
+            call("eventad_gru_cell_fwd", _rp(w["GI1"][r0:r1]), _rp(w["GH1"][r0:r1]), _rp(w["S1"][r0:r1]), NT, 256,
+                 _rp(w["G1"][r0:r1]), _rp(w["H1n"][r0:r1]), None, None, st)
+            call("eventad_gru_cell_fwd", _rp(w["GIC"][r0:r1]), _rp(w["GHC"][r0:r1]), _rp(w["SC"][r0:r1]), NT, 32,
+                 _rp(w["GC"][r0:r1]), _rp(w["HCn"][r0:r1]), None, None, st)
+            call("eventad_att_fwd", _rp(w["H0n"][r0:r1]), _rp(w["S0"][r0:r1]), _rp(vb), _rp(P["soft_attention.weight"]), 256,
+                 _rp(w["AL0"][r0:r1]), _rp(w["S0"][r1:r1 + NT]), st)
+            call("eventad_att_fwd", _rp(w["H1n"][r0:r1]), _rp(w["S1"][r0:r1]), _rp(vb), _rp(P["soft_attention.weight"]), 256,
+                 _rp(w["AL1"][r0:r1]), _rp(w["S1"][r1:r1 + NT]), st)
+            call("eventad_att_fwd", _rp(w["HCn"][r0:r1]), _rp(w["SC"][r0:r1]), _rp(vb), _rp(P["soft_attention_cor.weight"]), 32,
+                 _rp(w["ALC"][r0:r1]), _rp(w["SC"][r1:r1 + NT]), st)
+        # fusion MLP on all rows at once (Fuse_GRUNet.forward, EventAD.py:30-59)
+        g(0, 1, w["H1n"], 256, P[fu + "event_proj.weight"], 256, w["ZCAT"], 512, R, 256, 256, bias=P[fu + "event_proj.bias"])
+        g(0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, bias=P[fu + "coord_proj.bias"])
+        g(0, 1, w["ZCAT"], 512, P[fu + "fusion.0.weight"], 512, w["F1r"], 256, R, 256, 512, bias=P[fu + "fusion.0.bias"], relu=1)
+        call("eventad_fuse_out", ptr(w["F1r"]), _rp(self.D2), _rp(P[fu + "fusion.3.weight"]), _rp(P[fu + "fusion.3.bias"]),
+             ptr(w["target"]), ptr(w["valid"]), R, ptr(w["logits"]), ptr(w["dlog"]), ptr(w["loss_rows"]), ptr(w["loss"]), st)
+        self._fw = (B, train)
+        return (w["loss"][0], w["logits"].view(B, NT, 2), w["valid"].view(B, NT).bool(), w["target"].view(B, NT).long())
+
+    # ----------------------------------------------------------------- backward
+    def backward(self):
+        """Fills `self.grads` (d loss / d every used parameter) for the last forward."""
+        B, train = self._fw
+        w, P, G, g = self.w, self.P, self.G, self._gemm
+        st = torch.cuda.current_stream().cuda_stream
+        R = B * NT
+        ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
+        self.grads.zero_()
+        call("eventad_out_bwd", ptr(w["dlog"]), _rp(P[fu + "fusion.3.weight"]), ptr(w["F1r"]), _rp(self.D2), R, ptr(w["dPre"]),
+             _rp(G[fu + "fusion.3.weight"]), _rp(G[fu + "fusion.3.bias"]), st)
+        g(1, 0, w["dPre"], 256, w["ZCAT"], 512, G[fu + "fusion.0.weight"], 512, 256, 512, R)
+        call("eventad_colsum", ptr(w["dPre"]), 256, R, 256, _rp(G[fu + "fusion.0.bias"]), st)
+        g(0, 0, w["dPre"], 256, P[fu + "fusion.0.weight"], 512, w["dZCAT"], 512, R, 512, 256)
+        dE, dC = w["dZCAT"], w["dZCAT"][:, 256:]
+        g(1, 0, dE, 512, w["H1n"], 256, G[fu + "event_proj.weight"], 256, 256, 256, R)
+        call("eventad_colsum", _rp(dE), 512, R, 256, _rp(G[fu + "event_proj.bias"]), st)
+        g(0, 0, dE, 512, P[fu + "event_proj.weight"], 256, w["dH1o"], 256, R, 256, 256)
+        g(1, 0, dC, 512, w["HCn"], 32, G[fu + "coord_proj.weight"], 32, 256, 32, R)
+        call("eventad_colsum", _rp(dC), 512, R, 256, _rp(G[fu + "coord_proj.bias"]), st)
+        g(0, 0, dC, 512, P[fu + "coord_proj.weight"], 32, w["dHCo"], 32, R, 32, 256)
+        d0, d1, dc = w["dS0a"], w["dS1a"], w["dSCa"]
+        n0, n1, nc = w["dS0b"], w["dS1b"], w["dSCb"]
+        d0.zero_(); d1.zero_(); dc.zero_()
+        watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
+        gatt, gattc = G["soft_attention.weight"], G["soft_attention_cor.weight"]
+        for b in range(B - 1, -1, -1):
+            r0, r1 = b * NT, (b + 1) * NT
+            vb = w["valid"][r0:r1]
+            call("eventad_att_bwd", _rp(d1), _rp(w["dH1o"][r0:r1]), _rp(w["H1n"][r0:r1]), _rp(w["AL1"][r0:r1]), _rp(vb), _rp(watt),
+                 256, _rp(w["dHn1"]), _rp(w["dSp1"]), _rp(gatt), st)
+            call("eventad_att_bwd", _rp(dc), _rp(w["dHCo"][r0:r1]), _rp(w["HCn"][r0:r1]), _rp(w["ALC"][r0:r1]), _rp(vb), _rp(wattc),
+                 32, _rp(w["dHnC"]), _rp(w["dSpC"]), _rp(gattc), st)
+            call("eventad_att_bwd", _rp(d0), None, _rp(w["H0n"][r0:r1]), _rp(w["AL0"][r0:r1]), _rp(vb), _rp(watt),
+                 256, _rp(w["dHn0"]), _rp(w["dSp0"]), _rp(gatt), st)
+            call("eventad_gru_cell_bwd", _rp(w["dHn1"]), None, None, _rp(w["G1"][r0:r1]), _rp(w["GH1"][r0:r1]), _rp(w["S1"][r0:r1]),
+                 _rp(w["dSp1"]), NT, 256, _rp(w["dGI1"][r0:r1]), _rp(w["dGH1"][r0:r1]), _rp(n1), st)
+            call("eventad_gru_cell_bwd", _rp(w["dHnC"]), None, None, _rp(w["GC"][r0:r1]), _rp(w["GHC"][r0:r1]), _rp(w["SC"][r0:r1]),
+                 _rp(w["dSpC"]), NT, 32, _rp(w["dGIC"][r0:r1]), _rp(w["dGHC"][r0:r1]), _rp(nc), st)
+            g(0, 0, w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, acc=1)
+            g(0, 0, w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, acc=1)
+            g(0, 0, w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768)
+            dm = self.D1[r0:r1] if train else None
+            call("eventad_gru_cell_bwd", _rp(w["dHn0"]), _rp(w["dX1"]), _rp(dm), _rp(w["G0"][r0:r1]), _rp(w["GH0"][r0:r1]),
+                 _rp(w["S0"][r0:r1]), _rp(w["dSp0"]), NT, 256, _rp(w["dGI0"][r0:r1]), _rp(w["dGH0"][r0:r1]), _rp(n0), st)
+            g(0, 0, w["dGH0"][r0:r1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, acc=1)
+            d0, n0 = n0, d0
+            d1, n1 = n1, d1
+            dc, nc = nc, dc
+        # weight gradients of the recurrent layers, batched over all clips
+        for pre, dgi, dgh, xin, sst, hin, hh in ((ev, "dGI0", "dGH0", "X", "S0", 64, 256), (ev, "dGI1", "dGH1", "X1", "S1", 256, 256),
+                                                 (co, "dGIC", "dGHC", "CO", "SC", 4, 32)):
+            sfx = "_l1" if dgi == "dGI1" else "_l0"
+            n3 = 3 * hh
+            g(1, 0, w[dgi], n3, w[xin], hin, G[pre + "weight_ih" + sfx], hin, n3, hin, R)
+            g(1, 0, w[dgh], n3, w[sst], hh, G[pre + "weight_hh" + sfx], hh, n3, hh, R)
+            call("eventad_colsum", ptr(w[dgi]), n3, R, n3, _rp(G[pre + "bias_ih" + sfx]), st)
+            call("eventad_colsum", ptr(w[dgh]), n3, R, n3, _rp(G[pre + "bias_hh" + sfx]), st)
+
+    # ---------------------------------------------------------------- optimiser
+    def optimizer_step(self):
+        """clip_grad_norm_(grad_clip) + AdamW on the flat buffers; returns the (pre-clip) gradient norm."""
+        call("eventad_clip_adamw", ptr(self.flat), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
+             float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), float(self.clip),
+             ptr(self.partial), ptr(self.opt_state), torch.cuda.current_stream().cuda_stream)
+        return self.opt_state[1]
+
+    def nonfinite_steps(self):
+        return int(self.opt_state[5].item())

@@ -19,6 +19,26 @@ import torch.nn.functional as F
 
 from .._lib import call, ptr
 
+
+class _NativeHeadFn(torch.autograd.Function):
+    """Autograd bridge so the reference's own loop (`loss.backward(); clip; optimizer.step()`,
+    utils/train.py:141-152) works on the HIP head: forward/backward are the native kernels."""
+
+    @staticmethod
+    def forward(ctx, nh, feats, bbox, bbox_batch, labels, B, W, H, train, *params):
+        loss, logits, valid, targets = nh.forward(feats, bbox, bbox_batch, labels, B, W, H, train)
+        ctx.nh = nh
+        ctx.mark_non_differentiable(logits, valid, targets)
+        return loss.clone(), logits, valid, targets
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        nh = ctx.nh
+        nh.backward()
+        from ..head_native import PARAMS
+        grads = tuple(nh.G[n] * g_loss for n, _ in PARAMS)
+        return (None,) * 9 + grads
+
 MAX_BOXES = 30
 T = MAX_BOXES + 1          # track slots 0..30 (slot 0 unused, as in the reference's [31, C] rows)
 
@@ -153,7 +173,10 @@ class EventADModel(nn.Module):
         return coords, targets, valid
 
     def head(self, feats, data, labels):
-        """Static masked restatement of EventAD.py:211-327 -> (loss, logits [B,T,2], valid [B,T], targets [B,T])."""
+        """The same static masked formulation written with torch ops (device agnostic).  NOT on the
+        product path (forward/loss_only run csrc/head.hip): it is the autograd cross-check of the HIP
+        head in tests/ and pins the masked formulation to the reference's golden vectors on CPU.
+        -> (loss, logits [B,T,2], valid [B,T], targets [B,T])."""
         B, dev = feats.shape[0], feats.device
         coords, targets, valid = self._tables(feats, data, labels)
         ge, gc = self.gru_net_event.gru, self.gru_net_cor.gru
@@ -180,9 +203,34 @@ class EventADModel(nn.Module):
             hc = torch.where(vm, attc[0], hc)
         return loss, torch.stack(logits_all), valid, targets
 
+    def native_head(self, **opt):
+        """The HIP head bound to this model's parameters (created on first use; re-created if the
+        parameters were moved).  There is no CPU path: a CPU model raises here."""
+        from ..head_native import NativeHead
+        nh = getattr(self, "_nh", None)
+        if nh is None or not nh.bound():
+            if self.soft_attention.weight.device.type != "cuda":
+                raise RuntimeError("EventADModel: the hot path runs on the GPU only (no CPU fallback); move the model to cuda")
+            nh = NativeHead(self, **opt)
+            object.__setattr__(self, "_nh", nh)
+        return nh
+
+    def _head_native(self, feats, data, labels):
+        from ..head_native import PARAMS
+        nh = self.native_head()
+        B = int(data.num_graphs)
+        W, H = int(self.dagr_model.width), int(self.dagr_model.height)
+        bbox, bb = getattr(data, "bbox", None), getattr(data, "bbox_batch", None)
+        if torch.is_grad_enabled():
+            params = dict(self.named_parameters())
+            return _NativeHeadFn.apply(nh, feats, bbox, bb, labels, B, W, H, self.training, *[params[n] for n, _ in PARAMS])
+        loss, logits, valid, targets = nh.forward(feats, bbox, bb, labels, B, W, H, self.training)
+        return loss.clone(), logits, valid, targets
+
     def forward(self, data, labels=None, testing=False):
         feats = self.extract_features(data, frames=(0, 1))
-        loss, logits, valid, targets = self.head(feats, data, labels)
+        loss, logits, valid, targets = self._head_native(feats, data, labels)
+        logits, valid, targets = logits[:, :T], valid[:, :T], targets[:, :T]
         losses = {"cross_entropy": loss}
         v = valid.cpu()                                                     # API boundary: nested lists need the host
         all_outputs, all_labels = [], []
@@ -197,4 +245,4 @@ class EventADModel(nn.Module):
         """Sync-free training path: features of the current frame only (the previous-frame features are
         computed by the reference but never read by forward, EventAD.py:216)."""
         feats = self.extract_features(data, frames=(1,))
-        return self.head(feats, data, labels)
+        return self._head_native(feats, data, labels)

@@ -17,6 +17,15 @@ class TrainStep:
     def __init__(self, model, lr=1e-3, weight_decay=1e-5, grad_clip=1.0, process_group=None, fused=None):
         self.model = model
         self.grad_clip = grad_clip
+        self.native = next(model.gru_net_event.parameters()).device.type == "cuda"
+        if self.native:
+            # product path: HIP head + fused clip/AdamW on flat buffers; ONE all-reduce on the flat gradient
+            self.nh = model.native_head(lr=lr, weight_decay=weight_decay, grad_clip=grad_clip)
+            self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+            self.group = process_group
+            self.bucket = self.nh.grads
+            self.bucket_bytes = 4 * self.nh.n
+            return
         self.params = [p for n, p in model.named_parameters()
                        if p.requires_grad and not n.startswith("dagr_model.")]
         self.used = [p for n, p in model.named_parameters()
@@ -70,6 +79,14 @@ class TrainStep:
         """data: formatted batch on the device.  Returns (loss, grad_norm) as device tensors."""
         if labels is None:
             labels = data.bbox[:, 4]
+        if self.native:
+            with torch.no_grad():
+                loss, logits, valid, targets = self.model.loss_only(data, labels)
+                self.nh.backward()
+                if self.world > 1:
+                    dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
+                norm = self.nh.optimizer_step()
+            return loss, norm
         self.opt.zero_grad(set_to_none=True)
         loss, logits, valid, targets = self.model.loss_only(data, labels)
         norm = self.backward_and_update(loss)
@@ -84,5 +101,9 @@ class TrainStep:
         return loss.detach(), norm
 
     def check(self):
-        if int(self.nonfinite.item()) != 0:
+        if self.native:
+            bad = self.nh.nonfinite_steps()
+        else:
+            bad = int(self.nonfinite.item())
+        if bad != 0:
             raise ValueError("non-finite gradient norm seen in a training step (reference raises at utils/train.py:147-149)")

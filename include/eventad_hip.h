@@ -131,6 +131,38 @@ int eventad_roi_pool(const float* node_x, const float* node_pos, const int32_t* 
                      int n_max, const float* bbox, const int64_t* bbox_batch, int M, int frame, int n_frames,
                      int width, int height, int B, float* feats, void* stream);
 
+/* General GEMM form used by the head: trans_a / trans_b select the stored layout ([M,K] vs [K,M],
+ * [K,N] vs [N,K] = PyTorch's Linear weight); accumulate != 0 adds into C.  Replaces the M=1 cuDNN /
+ * cuBLAS calls behind nn.GRU / nn.Linear in the reference head (models/EventAD.py:16-28,67,86). */
+int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        int M, int N, int K, const float* bias, int relu, int accumulate, void* stream);
+/* (clip, track) tables + current-frame feature gather: replaces EventAD.py:229-255.  X f32[B*32,64],
+ * CO f32[B*32,4], target/valid i32[B*32]; labels = bbox[:,4] (nullable). */
+int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, const float* labels, const float* feats,
+                        int B, int width, int height, float* X, float* CO, int32_t* target, int32_t* valid, void* stream);
+/* One nn.GRU layer time step, element-wise part (gate order r,z,n) and its backward. */
+int eventad_gru_cell_fwd(const float* gi, const float* gh, const float* hprev, int rows, int H, float* gates,
+                         float* hnew, const float* mask, float* xdrop, void* stream);
+int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* mask, const float* gates, const float* gh,
+                         const float* hprev, const float* dspass, int rows, int H, float* dgi, float* dgh, float* dsprev,
+                         void* stream);
+/* SpatialAttention over the valid tracks of one clip (EventAD.py:100-138, 320-323) and its backward. */
+int eventad_att_fwd(const float* Hn, const float* Sprev, const int32_t* valid, const float* w, int H, float* alpha,
+                    float* Snext, void* stream);
+int eventad_att_bwd(const float* dSnext, const float* dHn_out, const float* Hn, const float* alpha, const int32_t* valid,
+                    const float* w, int H, float* dHn, float* dSpass, float* dw, void* stream);
+/* fusion[3] Linear(256,2) + summed cross-entropy (EventAD.py:27,280-281) and its backward. */
+int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
+                     const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss, void* stream);
+int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
+                    float* dWo, float* dbo, void* stream);
+int eventad_colsum(const float* A, int lda, int R, int N, float* out, void* stream);
+/* clip_grad_norm_ + AdamW on flat buffers (utils/train.py:27-53,141-152).  state f32[8]:
+ * [0] step, [1] grad norm, [2] clip coefficient, [3] 1-beta1^t, [4] 1-beta2^t, [5] non-finite-norm count. */
+int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, double max_norm, float* partial, float* state,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
