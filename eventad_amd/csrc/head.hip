@@ -123,85 +123,114 @@ extern "C" int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// SpatialAttention (EventAD.py:100-138) over the valid tracks of one clip, one block per call:
+// SpatialAttention (EventAD.py:100-138) over the valid tracks of one clip; up to 3 independent
+// problems (event GRU layer 0, layer 1, coordinate GRU) per launch, one workgroup each:
 //   s_k = tanh(Hn_k).w ; alpha = softmax_valid(s) ; S'_k = valid ? Hn_k*alpha_k : S_k (state kept)
-__global__ __launch_bounds__(256) void k_att_fwd(const float* __restrict__ Hn, const float* __restrict__ Sprev,
-                                                 const int* __restrict__ valid, const float* __restrict__ w, int H,
-                                                 float* __restrict__ alpha, float* __restrict__ Snext) {
+struct AttProb { const float* Hn; const float* Sprev; const float* w; float* alpha; float* Snext;
+                 const float* dSnext; const float* dHn_out; float* dHn; float* dSpass; float* dw; int H; };
+struct AttGroup { AttProb p[3]; const int* valid; int n; };
+
+__device__ __forceinline__ float wave_sum(float v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64)); return v; }
+
+__global__ __launch_bounds__(256) void k_att_fwd(AttGroup g) {
     __shared__ float s_s[NT], s_a[NT];
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_v[NT];
+    const AttProb& P = g.p[blockIdx.x];
+    const int H = P.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < NT) s_v[threadIdx.x] = g.valid[threadIdx.x];
     for (int k = wave; k < NT; k += 4) {
         float acc = 0.f;
-        for (int j = lane; j < H; j += 64) acc += tanhf(Hn[(size_t)k * H + j]) * w[j];
-        for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+        for (int j = lane; j < H; j += 64) acc += tanhf(P.Hn[(size_t)k * H + j]) * P.w[j];
+        acc = wave_sum(acc);
         if (lane == 0) s_s[k] = acc;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = -3.4e38f; int any = 0;
-        for (int k = 0; k < NT; ++k) if (valid[k]) { m = fmaxf(m, s_s[k]); any = 1; }
-        float sum = 0.f;
-        for (int k = 0; k < NT; ++k) { float e = (any && valid[k]) ? expf(s_s[k] - m) : 0.f; s_a[k] = e; sum += e; }
-        for (int k = 0; k < NT; ++k) { float a = any && valid[k] ? s_a[k] / sum : 0.f; s_a[k] = a; alpha[k] = a; }
+    if (wave == 0) {                                         // masked softmax over the 32 track slots
+        bool v = lane < NT && s_v[lane];
+        float sv = v ? s_s[lane] : -3.4e38f;
+        float m = wave_max(sv);
+        float e = v ? expf(sv - m) : 0.f;
+        float sum = wave_sum(e);
+        float a = v ? e / sum : 0.f;
+        if (lane < NT) { s_a[lane] = a; P.alpha[lane] = a; }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < NT * H; t += 256) {
         int k = t / H;
-        Snext[t] = valid[k] ? Hn[t] * s_a[k] : Sprev[t];
+        P.Snext[t] = s_v[k] ? P.Hn[t] * s_a[k] : P.Sprev[t];
     }
 }
 
-extern "C" int eventad_att_fwd(const float* Hn, const float* Sprev, const int32_t* valid, const float* w, int H,
-                               float* alpha, float* Snext, void* stream) {
-    if (!Hn || !Sprev || !valid || !w || !alpha || !Snext || H <= 0) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_att_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, Hn, Sprev, valid, w, H, alpha, Snext);
-    return evad_last_error();
-}
-
-// backward of the above: dHn (total, incl. dHn_out from the fusion branch), dSpass (rows whose state
-// was kept), dw += this clip's contribution (deterministic: one thread per j sums the tracks in order).
-__global__ __launch_bounds__(256) void k_att_bwd(const float* __restrict__ dSnext, const float* __restrict__ dHn_out,
-                                                 const float* __restrict__ Hn, const float* __restrict__ alpha,
-                                                 const int* __restrict__ valid, const float* __restrict__ w, int H,
-                                                 float* __restrict__ dHn, float* __restrict__ dSpass, float* __restrict__ dw) {
-    __shared__ float s_da[NT], s_ds[NT];
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// backward: dHn (total, incl. dHn_out from the fusion / next-layer branch), dSpass (rows whose state was
+// kept), dw += this clip's contribution (deterministic: fixed summation order inside one workgroup).
+__global__ __launch_bounds__(256) void k_att_bwd(AttGroup g) {
+    __shared__ float s_da[NT], s_ds[NT], s_al[NT];
+    __shared__ int s_v[NT];
+    const AttProb& P = g.p[blockIdx.x];
+    const int H = P.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < NT) { s_v[threadIdx.x] = g.valid[threadIdx.x]; s_al[threadIdx.x] = P.alpha[threadIdx.x]; }
+    __syncthreads();
     for (int k = wave; k < NT; k += 4) {
         float acc = 0.f;
-        if (valid[k]) for (int j = lane; j < H; j += 64) acc += dSnext[(size_t)k * H + j] * Hn[(size_t)k * H + j];
-        for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+        if (s_v[k]) for (int j = lane; j < H; j += 64) acc += P.dSnext[(size_t)k * H + j] * P.Hn[(size_t)k * H + j];
+        acc = wave_sum(acc);
         if (lane == 0) s_da[k] = acc;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float dot = 0.f;
-        for (int k = 0; k < NT; ++k) if (valid[k]) dot += alpha[k] * s_da[k];
-        for (int k = 0; k < NT; ++k) s_ds[k] = valid[k] ? alpha[k] * (s_da[k] - dot) : 0.f;
+    if (wave == 0) {
+        bool v = lane < NT && s_v[lane];
+        float a = v ? s_al[lane] : 0.f, da = v ? s_da[lane] : 0.f;
+        float dot = wave_sum(a * da);
+        if (lane < NT) s_ds[lane] = v ? a * (da - dot) : 0.f;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < NT * H; t += 256) {
         int k = t / H, j = t % H;
-        float g = dSnext[t];
-        if (valid[k]) {
-            float th = tanhf(Hn[t]);
-            float d = g * alpha[k] + s_ds[k] * w[j] * (1.f - th * th);
-            if (dHn_out) d += dHn_out[t];
-            dHn[t] = d; dSpass[t] = 0.f;
-        } else { dHn[t] = 0.f; dSpass[t] = g; }
+        float gr = P.dSnext[t];
+        if (s_v[k]) {
+            float th = tanhf(P.Hn[t]);
+            float d = gr * s_al[k] + s_ds[k] * P.w[j] * (1.f - th * th);
+            if (P.dHn_out) d += P.dHn_out[t];
+            P.dHn[t] = d; P.dSpass[t] = 0.f;
+        } else { P.dHn[t] = 0.f; P.dSpass[t] = gr; }
     }
     for (int j = threadIdx.x; j < H; j += 256) {
         float acc = 0.f;
-        for (int k = 0; k < NT; ++k) if (valid[k]) acc += s_ds[k] * tanhf(Hn[(size_t)k * H + j]);
-        dw[j] += acc;
+        for (int k = 0; k < NT; ++k) if (s_v[k]) acc += s_ds[k] * tanhf(P.Hn[(size_t)k * H + j]);
+        P.dw[j] += acc;                 // every problem of a launch owns its own dw accumulator
     }
 }
 
-extern "C" int eventad_att_bwd(const float* dSnext, const float* dHn_out, const float* Hn, const float* alpha,
-                               const int32_t* valid, const float* w, int H, float* dHn, float* dSpass, float* dw,
-                               void* stream) {
-    if (!dSnext || !Hn || !alpha || !valid || !w || !dHn || !dSpass || !dw || H <= 0) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_att_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dSnext, dHn_out, Hn, alpha, valid, w, H, dHn,
-                       dSpass, dw);
+/* desc: HOST array, 12 int64 per problem: [0] Hn [1] Sprev [2] w [3] alpha [4] Snext [5] dSnext [6] dHn_out
+ * [7] dHn [8] dSpass [9] dw [10] H.  fwd uses 0-4,10; bwd uses 0,2,3,5-10. */
+static int att_group(int n, const int64_t* d, const int32_t* valid, AttGroup* g) {
+    if (n < 1 || n > 3 || !d || !valid) return EVAD_ERR_ARG;
+    g->n = n; g->valid = valid;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* q = d + 12 * i;
+        AttProb& P = g->p[i];
+        P.Hn = (const float*)q[0]; P.Sprev = (const float*)q[1]; P.w = (const float*)q[2]; P.alpha = (float*)q[3];
+        P.Snext = (float*)q[4]; P.dSnext = (const float*)q[5]; P.dHn_out = (const float*)q[6]; P.dHn = (float*)q[7];
+        P.dSpass = (float*)q[8]; P.dw = (float*)q[9]; P.H = (int)q[10];
+        if (!P.Hn || !P.w || !P.alpha || P.H <= 0) return EVAD_ERR_ARG;
+    }
+    return EVAD_OK;
+}
+
+extern "C" int eventad_att_fwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream) {
+    AttGroup g;
+    if (att_group(n_prob, desc, valid, &g)) return EVAD_ERR_ARG;
+    for (int i = 0; i < n_prob; ++i) if (!g.p[i].Sprev || !g.p[i].Snext) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_att_fwd, dim3(n_prob), dim3(256), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}
+
+extern "C" int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream) {
+    AttGroup g;
+    if (att_group(n_prob, desc, valid, &g)) return EVAD_ERR_ARG;
+    for (int i = 0; i < n_prob; ++i) if (!g.p[i].dSnext || !g.p[i].dHn || !g.p[i].dSpass || !g.p[i].dw) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_att_bwd, dim3(n_prob), dim3(256), 0, (hipStream_t)stream, g);
     return evad_last_error();
 }
 
@@ -251,42 +280,56 @@ extern "C" int eventad_fuse_out(const float* F1r, const float* D2, const float* 
     return evad_last_error();
 }
 
-// backward of the output layer: dWo, dbo, and dPre[R,256] = (dlog.Wo) * D2 * [F1r > 0]
-__global__ void k_out_bwd(const float* __restrict__ dlog, const float* __restrict__ Wo, const float* __restrict__ F1r,
-                          const float* __restrict__ D2, int R, float* __restrict__ dPre, float* __restrict__ dWo,
-                          float* __restrict__ dbo) {
-    int j = threadIdx.x;                                    // 256 threads, one block
-    float w0 = Wo[j], w1 = Wo[256 + j], g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
-    for (int r = 0; r < R; ++r) {
+// backward of the output layer: dPre[R,256] = (dlog.Wo) * D2 * [F1r > 0]  (one thread per element),
+// dWo[c][j] = sum_r dlog[r][c] * F1[r][j], dbo[c] = sum_r dlog[r][c]  (one wave per column j, rows in
+// lane-strided order then a fixed shuffle tree: reproducible).
+__global__ void k_out_bwd_pre(const float* __restrict__ dlog, const float* __restrict__ Wo, const float* __restrict__ F1r,
+                              const float* __restrict__ D2, int R, float* __restrict__ dPre) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * 256) return;
+    int r = t >> 8, j = t & 255;
+    float m = D2 ? D2[t] : 1.f;
+    dPre[t] = F1r[t] > 0.f ? (dlog[2 * r] * Wo[j] + dlog[2 * r + 1] * Wo[256 + j]) * m : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_out_bwd_w(const float* __restrict__ dlog, const float* __restrict__ F1r,
+                                                   const float* __restrict__ D2, int R, float* __restrict__ dWo,
+                                                   float* __restrict__ dbo) {
+    int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;       // 64 blocks x 4 waves = 256 columns
+    float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
+    for (int r = lane; r < R; r += 64) {
         float d0 = dlog[2 * r], d1 = dlog[2 * r + 1];
-        float fr = F1r[(size_t)r * 256 + j], m = D2 ? D2[(size_t)r * 256 + j] : 1.f;
-        float f = fr * m;
+        float f = F1r[(size_t)r * 256 + j] * (D2 ? D2[(size_t)r * 256 + j] : 1.f);
         g0 += d0 * f; g1 += d1 * f; b0 += d0; b1 += d1;
-        dPre[(size_t)r * 256 + j] = fr > 0.f ? (d0 * w0 + d1 * w1) * m : 0.f;
     }
-    dWo[j] = g0; dWo[256 + j] = g1;
-    if (j == 0) { dbo[0] = b0; dbo[1] = b1; }
+    g0 = wave_sum(g0); g1 = wave_sum(g1); b0 = wave_sum(b0); b1 = wave_sum(b1);
+    if (lane == 0) { dWo[j] = g0; dWo[256 + j] = g1; if (j == 0) { dbo[0] = b0; dbo[1] = b1; } }
 }
 
 extern "C" int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
                                float* dWo, float* dbo, void* stream) {
     if (!dlog || !Wo || !F1r || !dPre || !dWo || !dbo || R <= 0) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_out_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dlog, Wo, F1r, D2, R, dPre, dWo, dbo);
+    hipLaunchKernelGGL(k_out_bwd_pre, dim3(evad_blocks((long long)R * 256, 256)), dim3(256), 0, (hipStream_t)stream, dlog, Wo,
+                       F1r, D2, R, dPre);
+    hipLaunchKernelGGL(k_out_bwd_w, dim3(64), dim3(256), 0, (hipStream_t)stream, dlog, F1r, D2, R, dWo, dbo);
     return evad_last_error();
 }
 
-// column sums (bias gradients): out[n] = sum_r A[r, n]
-__global__ void k_colsum(const float* __restrict__ A, int lda, int R, int N, float* __restrict__ out) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// column sums (bias gradients): out[n] = sum_r A[r, n]; 64 columns per workgroup, the 4 waves split the
+// rows, fixed-order LDS reduction.
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int lda, int R, int N, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += A[(size_t)r * lda + n];
-    out[n] = s;
+    if (n < N) for (int r = w; r < R; r += 4) s += A[(size_t)r * lda + n];
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && n < N) out[n] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 extern "C" int eventad_colsum(const float* A, int lda, int R, int N, float* out, void* stream) {
     if (!A || !out || R <= 0 || N <= 0 || lda < N) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_colsum, dim3(evad_blocks(N, 64)), dim3(64), 0, (hipStream_t)stream, A, lda, R, N, out);
+    hipLaunchKernelGGL(k_colsum, dim3(evad_blocks(N, 64)), dim3(256), 0, (hipStream_t)stream, A, lda, R, N, out);
     return evad_last_error();
 }
 

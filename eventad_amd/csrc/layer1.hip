@@ -94,7 +94,11 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     dim3 grid(evad_blocks(N, 64)), block(256);
     if (with_lut <= 80 * 1024) {            // two workgroups per CU (160 KiB LDS)
         auto kern = k_l1_conv<CINP, SKIP, true>;
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)with_lut);
+        static size_t attr_set = 0;                 // raise the dynamic-LDS limit once per size (not a stream op)
+        if (attr_set < with_lut) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)with_lut);
+            attr_set = with_lut;
+        }
         hipLaunchKernelGGL(kern, grid, block, with_lut, st, xin, ell_src, ell_step, deg, lut, root, scale, shift, xskip,
                            wskip, sscale, sshift, out, N, steps, max_nb);
     } else {                                // large radius: LUT stays in global memory / L2

@@ -94,7 +94,28 @@ class NativeHead:
         for k, n in (("dS0a", 256), ("dS0b", 256), ("dS1a", 256), ("dS1b", 256), ("dSCa", 32), ("dSCb", 32),
                      ("dHn0", 256), ("dHn1", 256), ("dHnC", 32), ("dSp0", 256), ("dSp1", 256), ("dSpC", 32), ("dX1", 256)):
             w[k] = f(NT, n)
+        w["part"] = [f(12 * 32 * 768) for _ in range(4)]                        # split-K slabs, one per grouped problem
+        w["dwatt0"], w["dwatt1"] = f(256), f(256)                               # per-layer accumulators of d soft_attention.weight
         self._B = B
+
+    def _m32(self, *probs):
+        """Grouped skinny GEMMs: each prob = (A, lda, B, ldb, C, ldc, M, N, K, trans_b, bias, accumulate)."""
+        d = (ctypes.c_int64 * (16 * len(probs)))()
+        for i, (A, lda, Bm, ldb, C, ldc, M, N, K, tb, bias, acc) in enumerate(probs):
+            d[16 * i:16 * i + 13] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr(), C.data_ptr(),
+                                     bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, tb, acc]
+        call("eventad_gemm_m32_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
+
+    def _att(self, fn, valid, *probs):
+        """Grouped attentions: prob = dict(Hn, Sprev, w, alpha, Snext, dSnext, dHn_out, dHn, dSpass, dw, H)."""
+        keys = ("Hn", "Sprev", "w", "alpha", "Snext", "dSnext", "dHn_out", "dHn", "dSpass", "dw")
+        d = (ctypes.c_int64 * (12 * len(probs)))()
+        for i, pr in enumerate(probs):
+            for j, k in enumerate(keys):
+                t = pr.get(k)
+                d[12 * i + j] = t.data_ptr() if t is not None else 0
+            d[12 * i + 10] = pr["H"]
+        call(fn, len(probs), ctypes.cast(d, ctypes.c_void_p), _rp(valid), torch.cuda.current_stream().cuda_stream)
 
     @staticmethod
     def _gemm(ta, tb, A, lda, Bm, ldb, C, ldc, M, N, K, bias=None, relu=0, acc=0):
@@ -123,26 +144,25 @@ class NativeHead:
         g(0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, bias=P[ev + "bias_ih_l0"])
         g(0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, bias=P[co + "bias_ih_l0"])
         w["S0"][:NT].zero_(); w["S1"][:NT].zero_(); w["SC"][:NT].zero_()
+        watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
         for b in range(B):                                     # the clip-to-clip hidden-state chain (EventAD.py:211-323)
             r0, r1 = b * NT, (b + 1) * NT
             vb = w["valid"][r0:r1]
-            g(0, 1, w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, bias=P[ev + "bias_hh_l0"])
-            g(0, 1, w["S1"][r0:r1], 256, P[ev + "weight_hh_l1"], 256, w["GH1"][r0:r1], 768, NT, 768, 256, bias=P[ev + "bias_hh_l1"])
-            g(0, 1, w["SC"][r0:r1], 32, P[co + "weight_hh_l0"], 32, w["GHC"][r0:r1], 96, NT, 96, 32, bias=P[co + "bias_hh_l0"])
+            self._m32((w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, 1, P[ev + "bias_hh_l0"], 0),
+                      (w["S1"][r0:r1], 256, P[ev + "weight_hh_l1"], 256, w["GH1"][r0:r1], 768, NT, 768, 256, 1, P[ev + "bias_hh_l1"], 0),
+                      (w["SC"][r0:r1], 32, P[co + "weight_hh_l0"], 32, w["GHC"][r0:r1], 96, NT, 96, 32, 1, P[co + "bias_hh_l0"], 0))
             d1 = self.D1[r0:r1] if train else None
             call("eventad_gru_cell_fwd", _rp(w["GI0"][r0:r1]), _rp(w["GH0"][r0:r1]), _rp(w["S0"][r0:r1]), NT, 256,
                  _rp(w["G0"][r0:r1]), _rp(w["H0n"][r0:r1]), _rp(d1), _rp(w["X1"][r0:r1]), st)
-            g(0, 1, w["X1"][r0:r1], 256, P[ev + "weight_ih_l1"], 256, w["GI1"][r0:r1], 768, NT, 768, 256, bias=P[ev + "bias_ih_l1"])
-            call("eventad_gru_cell_fwd", _rp(w["GI1"][r0:r1]), _rp(w["GH1"][r0:r1]), _rp(w["S1"][r0:r1]), NT, 256,
-                 _rp(w["G1"][r0:r1]), _rp(w["H1n"][r0:r1]), None, None, st)
             call("eventad_gru_cell_fwd", _rp(w["GIC"][r0:r1]), _rp(w["GHC"][r0:r1]), _rp(w["SC"][r0:r1]), NT, 32,
                  _rp(w["GC"][r0:r1]), _rp(w["HCn"][r0:r1]), None, None, st)
-            call("eventad_att_fwd", _rp(w["H0n"][r0:r1]), _rp(w["S0"][r0:r1]), _rp(vb), _rp(P["soft_attention.weight"]), 256,
-                 _rp(w["AL0"][r0:r1]), _rp(w["S0"][r1:r1 + NT]), st)
-            call("eventad_att_fwd", _rp(w["H1n"][r0:r1]), _rp(w["S1"][r0:r1]), _rp(vb), _rp(P["soft_attention.weight"]), 256,
-                 _rp(w["AL1"][r0:r1]), _rp(w["S1"][r1:r1 + NT]), st)
-            call("eventad_att_fwd", _rp(w["HCn"][r0:r1]), _rp(w["SC"][r0:r1]), _rp(vb), _rp(P["soft_attention_cor.weight"]), 32,
-                 _rp(w["ALC"][r0:r1]), _rp(w["SC"][r1:r1 + NT]), st)
+            self._m32((w["X1"][r0:r1], 256, P[ev + "weight_ih_l1"], 256, w["GI1"][r0:r1], 768, NT, 768, 256, 1, P[ev + "bias_ih_l1"], 0))
+            call("eventad_gru_cell_fwd", _rp(w["GI1"][r0:r1]), _rp(w["GH1"][r0:r1]), _rp(w["S1"][r0:r1]), NT, 256,
+                 _rp(w["G1"][r0:r1]), _rp(w["H1n"][r0:r1]), None, None, st)
+            self._att("eventad_att_fwd_group", vb,
+                      dict(Hn=w["H0n"][r0:r1], Sprev=w["S0"][r0:r1], w=watt, alpha=w["AL0"][r0:r1], Snext=w["S0"][r1:r1 + NT], H=256),
+                      dict(Hn=w["H1n"][r0:r1], Sprev=w["S1"][r0:r1], w=watt, alpha=w["AL1"][r0:r1], Snext=w["S1"][r1:r1 + NT], H=256),
+                      dict(Hn=w["HCn"][r0:r1], Sprev=w["SC"][r0:r1], w=wattc, alpha=w["ALC"][r0:r1], Snext=w["SC"][r1:r1 + NT], H=32))
         # fusion MLP on all rows at once (Fuse_GRUNet.forward, EventAD.py:30-59)
         g(0, 1, w["H1n"], 256, P[fu + "event_proj.weight"], 256, w["ZCAT"], 512, R, 256, 256, bias=P[fu + "event_proj.bias"])
         g(0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, bias=P[fu + "coord_proj.bias"])
@@ -177,30 +197,33 @@ class NativeHead:
         n0, n1, nc = w["dS0b"], w["dS1b"], w["dSCb"]
         d0.zero_(); d1.zero_(); dc.zero_()
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
-        gatt, gattc = G["soft_attention.weight"], G["soft_attention_cor.weight"]
+        gattc = G["soft_attention_cor.weight"]
+        w["dwatt0"].zero_(); w["dwatt1"].zero_()
         for b in range(B - 1, -1, -1):
             r0, r1 = b * NT, (b + 1) * NT
             vb = w["valid"][r0:r1]
-            call("eventad_att_bwd", _rp(d1), _rp(w["dH1o"][r0:r1]), _rp(w["H1n"][r0:r1]), _rp(w["AL1"][r0:r1]), _rp(vb), _rp(watt),
-                 256, _rp(w["dHn1"]), _rp(w["dSp1"]), _rp(gatt), st)
-            call("eventad_att_bwd", _rp(dc), _rp(w["dHCo"][r0:r1]), _rp(w["HCn"][r0:r1]), _rp(w["ALC"][r0:r1]), _rp(vb), _rp(wattc),
-                 32, _rp(w["dHnC"]), _rp(w["dSpC"]), _rp(gattc), st)
-            call("eventad_att_bwd", _rp(d0), None, _rp(w["H0n"][r0:r1]), _rp(w["AL0"][r0:r1]), _rp(vb), _rp(watt),
-                 256, _rp(w["dHn0"]), _rp(w["dSp0"]), _rp(gatt), st)
+            self._att("eventad_att_bwd_group", vb,
+                      dict(Hn=w["H1n"][r0:r1], w=watt, alpha=w["AL1"][r0:r1], dSnext=d1, dHn_out=w["dH1o"][r0:r1], dHn=w["dHn1"],
+                           dSpass=w["dSp1"], dw=w["dwatt1"], H=256),
+                      dict(Hn=w["HCn"][r0:r1], w=wattc, alpha=w["ALC"][r0:r1], dSnext=dc, dHn_out=w["dHCo"][r0:r1], dHn=w["dHnC"],
+                           dSpass=w["dSpC"], dw=gattc, H=32),
+                      dict(Hn=w["H0n"][r0:r1], w=watt, alpha=w["AL0"][r0:r1], dSnext=d0, dHn_out=None, dHn=w["dHn0"],
+                           dSpass=w["dSp0"], dw=w["dwatt0"], H=256))
             call("eventad_gru_cell_bwd", _rp(w["dHn1"]), None, None, _rp(w["G1"][r0:r1]), _rp(w["GH1"][r0:r1]), _rp(w["S1"][r0:r1]),
                  _rp(w["dSp1"]), NT, 256, _rp(w["dGI1"][r0:r1]), _rp(w["dGH1"][r0:r1]), _rp(n1), st)
             call("eventad_gru_cell_bwd", _rp(w["dHnC"]), None, None, _rp(w["GC"][r0:r1]), _rp(w["GHC"][r0:r1]), _rp(w["SC"][r0:r1]),
                  _rp(w["dSpC"]), NT, 32, _rp(w["dGIC"][r0:r1]), _rp(w["dGHC"][r0:r1]), _rp(nc), st)
-            g(0, 0, w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, acc=1)
-            g(0, 0, w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, acc=1)
-            g(0, 0, w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768)
+            self._m32((w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, 0, None, 1),
+                      (w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, 0, None, 1),
+                      (w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768, 0, None, 0))
             dm = self.D1[r0:r1] if train else None
             call("eventad_gru_cell_bwd", _rp(w["dHn0"]), _rp(w["dX1"]), _rp(dm), _rp(w["G0"][r0:r1]), _rp(w["GH0"][r0:r1]),
                  _rp(w["S0"][r0:r1]), _rp(w["dSp0"]), NT, 256, _rp(w["dGI0"][r0:r1]), _rp(w["dGH0"][r0:r1]), _rp(n0), st)
-            g(0, 0, w["dGH0"][r0:r1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, acc=1)
+            self._m32((w["dGH0"][r0:r1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, 0, None, 1))
             d0, n0 = n0, d0
             d1, n1 = n1, d1
             dc, nc = nc, dc
+        torch.add(w["dwatt0"], w["dwatt1"], out=G["soft_attention.weight"].view(-1))
         # weight gradients of the recurrent layers, batched over all clips
         for pre, dgi, dgh, xin, sst, hin, hh in ((ev, "dGI0", "dGH0", "X", "S0", 64, 256), (ev, "dGI1", "dGH1", "X1", "S1", 256, 256),
                                                  (co, "dGIC", "dGHC", "CO", "SC", 4, 32)):

@@ -92,6 +92,30 @@ class TrainStep:
         norm = self.backward_and_update(loss)
         return loss.detach(), norm
 
+    # ---- hipGraph: the whole step (backbone + ROI + head fwd/bwd + all-reduce + clip/AdamW) has no host
+    # sync, so it can be captured once and replayed -- the launch-bound head chain then costs graph-node
+    # boundaries (~1.5 us) instead of Python/ctypes launches.  The captured batch buffers are static:
+    # copy a new batch of the same shape into `data` before replay().
+    def capture(self, data, labels=None, warmup=3):
+        assert self.native, "graph capture is for the GPU path"
+        if labels is None:
+            labels = data.bbox[:, 4]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(data, labels)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._g_loss, self._g_norm = self.step(data, labels)
+        return self.graph
+
+    def replay(self):
+        self.graph.replay()
+        return self._g_loss, self._g_norm
+
     def step_from_feats(self, feats, data, labels=None):
         if labels is None:
             labels = data.bbox[:, 4]

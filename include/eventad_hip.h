@@ -147,10 +147,16 @@ int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* m
                          const float* hprev, const float* dspass, int rows, int H, float* dgi, float* dgh, float* dsprev,
                          void* stream);
 /* SpatialAttention over the valid tracks of one clip (EventAD.py:100-138, 320-323) and its backward. */
-int eventad_att_fwd(const float* Hn, const float* Sprev, const int32_t* valid, const float* w, int H, float* alpha,
-                    float* Snext, void* stream);
-int eventad_att_bwd(const float* dSnext, const float* dHn_out, const float* Hn, const float* alpha, const int32_t* valid,
-                    const float* w, int H, float* dHn, float* dSpass, float* dw, void* stream);
+/* Up to 3 independent attentions per launch.  desc = HOST array, 12 int64 per problem:
+ * [0] Hn [1] Sprev [2] w [3] alpha [4] Snext [5] dSnext [6] dHn_out(0=none) [7] dHn [8] dSpass [9] dw [10] H;
+ * valid i32[32] = the clip's track mask (device). */
+int eventad_att_fwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
+int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
+/* Up to 4 independent [M<=32,K]x[K,N] products per launch, split over K into partial slabs and summed in
+ * order (deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B [2] part scratch
+ * f32[ceil(K/64)][32][N] [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K [11] trans_b
+ * [12] accumulate. */
+int eventad_gemm_m32_group(int n_prob, const int64_t* desc, void* stream);
 /* fusion[3] Linear(256,2) + summed cross-entropy (EventAD.py:27,280-281) and its backward. */
 int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
                      const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss, void* stream);
