@@ -1,0 +1,92 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/eventad_hip.h declares
+(no compute calls without a GPU), host-only helpers, config merge, geometry constants."""
+import ctypes
+
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol():
+    from eventad_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 30
+    lib = _lib.load()
+    for name, argtypes in protos.items():
+        fn = getattr(lib, name)
+        assert fn.argtypes == argtypes and fn.restype is ctypes.c_int, name
+    for must in ("eventad_insert_in_queue", "eventad_insert_in_queue_single", "eventad_fill_edges",   # = ev_graph_cuda
+                 "eventad_sort_events", "eventad_build_ell", "eventad_l1_conv1", "eventad_l1_conv2",
+                 "eventad_pool_scatter", "eventad_gemm_f32", "eventad_tail_blend", "eventad_roi_pool",
+                 "eventad_gru_cell_fwd", "eventad_att_bwd_group", "eventad_clip_adamw"):
+        assert must in protos
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    from eventad_amd import _lib
+    lib = _lib.load()
+    assert lib.eventad_insert_in_queue(None, None, None, None, 1, 1, 1, 1, 1, None) == -1
+    assert lib.eventad_gemm_f32(None, 4, None, 4, None, 4, 1, None, 1, 1, None, None, None, None, 0, 0, None) == -1
+    assert lib.eventad_roi_pool(None, None, None, None, 0, None, None, 0, 0, 2, 64, 64, 1, None, None) == -1
+
+
+def test_spiral_table_matches_oracle():
+    from eventad_amd import spline
+    from oracle import graph as G
+    for r in (1, 3, 7):
+        assert torch.equal(spline.spiral_offsets(r), G.spiral((2 * r + 1) ** 2).long())
+
+
+def test_geometry_matches_oracle_config():
+    from eventad_amd.geometry import Geometry
+    from oracle import dagr_ref
+    for W, H in ((64, 64), (256, 256), (640, 480), (1280, 720)):
+        g, c = Geometry(W, H), dagr_ref.make_config(W, H, 4)
+        assert (g.radius_px, g.radius_px, g.eff_r) == c.lut[0]
+        for lv in range(4):
+            assert g.voxel[lv] == (float(c.voxel[lv][0]), float(c.voxel[lv][1]))
+            assert abs(g.cart_max[lv + 1] - float(c.cart_max[lv + 1])) == 0
+        assert g.grid == [(56, 40), (28, 20), (14, 10), (7, 5)]
+    assert Geometry(1280, 720).radius_px == 13 and Geometry(640, 480).radius_px == 7
+
+
+def test_layer1_lut_equals_reference_lut_reordered():
+    from eventad_amd import spline
+    from eventad_amd.geometry import Geometry
+    from oracle import dagr_ref
+    g = Geometry(256, 256)
+    w = torch.randn(25, 19, 16, generator=torch.Generator().manual_seed(0))
+    mine = spline.lut_by_spiral_step(w, g, 20)
+    ref, _ = dagr_ref.init_lut(w, 256, 256, rx=3, Mx=g.eff_r)
+    d = spline.spiral_offsets(3)
+    for s in range(49):
+        assert torch.allclose(mine[s, :19], ref[d[s, 0] + 3, d[s, 1] + 3], atol=1e-7)
+    assert float(mine[:, 19].abs().max()) == 0.0
+
+
+def test_config_merge_rule_and_defaults(tmp_path):
+    from eventad_amd.config.eventad_config import parse_eventad_args
+    a = parse_eventad_args([])
+    assert (a.radius, a.max_neighbors, a.pooling_dim_at_output, a.kernel_size) == (0.01, 16, "5x7", 5)
+    assert (a.batch_size, a.learning_rate, a.grad_clip, a.x_dim, a.h_dim, a.num_workers) == (6, 0.001, 1.0, 64, 256, 4)
+    b = parse_eventad_args(["--radius", "0.02", "--batch_size", "3"])      # a flag wins over the YAML
+    assert b.radius == 0.02 and b.batch_size == 3 and b.max_neighbors == 16
+    y = tmp_path / "e.yaml"
+    y.write_text("h_dim: 999\nextra_key: 5\n")
+    c = parse_eventad_args(["--eventad_config", str(y)])
+    assert c.h_dim == 256 and c.extra_key == 5                             # argparse default present -> YAML ignored
+
+
+def test_cpu_model_has_no_fallback():
+    from eventad_amd.models.EventAD import EventADModel
+    m = EventADModel(torch.nn.Module())
+    with pytest.raises(RuntimeError):
+        m.native_head()
+
+
+def test_format_data_matches_oracle():
+    from eventad_amd import synthetic
+    from eventad_amd.dagr.utils.buffers import format_data
+    from oracle import dagr_ref
+    raw = synthetic.make_batch(64, 48, 500, 2, with_image=True)
+    a, b = format_data(raw.clone()), dagr_ref.format_data(raw.clone())
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.x, b.x) and torch.equal(a.image, b.image) and a.t is None
