@@ -52,7 +52,7 @@ def algorithmic_bytes(N, E, B, W, H):
         "eventad_build_ell#1": 16 * N + 8 * E,                                   # S1
         "eventad_l1_conv1#1": E * (76 + 8) + N * (76 + 64),                      # S3
         "eventad_l1_conv2#1": E * (64 + 8) + N * (64 + 76 + 64),                 # S4
-        "eventad_pool_scatter#1": 256 * N + maps1 + N * (320 + 16) + B * 2240 * (320 + 12),   # S5 + S6
+        "eventad_pool_seg0#1": 256 * N + maps1 + N * (320 + 16) + B * 2240 * (320 + 12),   # S5 + S6
     }
 
 

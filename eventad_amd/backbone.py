@@ -65,6 +65,7 @@ class NativeBackbone:
                      bns=[v.to(dev) for v in spline.fold_bn(sd, q2 + "norm_skip.module.")])
             self.tail.append(t)
         self.w = {k: ([t.to(dev) for t in v] if isinstance(v, tuple) else v.to(dev)) for k, v in w.items()}
+        self.vox_tabs = [t.to(dev).contiguous() for t in g.pixel_voxel_tables()]     # px->cx, py->cy, vx_lo, vy_lo
 
     # ---------------------------------------------------------------- workspace
     def _alloc(self, N, B):
@@ -81,7 +82,7 @@ class NativeBackbone:
             scan_tmp=i32(max(P, 1 << 16) // 2048 + 4), sid_tmp=i32(N), sid=i32(N), long_list=i32(P),
             key_s=i32(N), ts_s=i32(N), posn_s=f32(N, 3), x0s=f32(N, 20),
             ell_src=i32(N, K), ell_step=torch.empty((N, K), dtype=torch.int16, device=dev), deg=i32(N),
-            y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N),
+            y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N), ovf_list=i32(max(N, 1)),
         )
         levels = []
         for lv in range(4):
@@ -147,7 +148,9 @@ class NativeBackbone:
         self._c("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
              N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
              ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["long_list"]), ptr(ws["counters"]),
-             ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), st)
+             ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
+             g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
+             ptr(ws["ovf_list"]), st)
         self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), st)
         self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
@@ -163,10 +166,11 @@ class NativeBackbone:
             mean = 1 if g.pool_aggr[lv] == "mean" else 0
             fmap = maps[lv + 1]
             if lv == 0:
-                self._c("eventad_pool_scatter", ptr(ws["y2"]), 16, 16, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
-                     ptr(ws["posn_s"]), None, None, ptr(ws["key_s"]), ptr(ws["sid"]), N, None, g.W, g.H, vsx, vsy,
-                     L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
-                     ptr(ws["node_slot0"]), ptr(ws["counters"]), st)
+                # wave-per-voxel segmented max over the pixel CSR (no atomics, no table memsets)
+                self._c("eventad_pool_seg0", ptr(ws["y2"]), ptr(fmap), fmap.shape[1], fmap.shape[2], ptr(ws["posn_s"]),
+                        ptr(ws["key_s"]), ptr(ws["sid"]), ptr(ws["node_slot0"]), ptr(ws["pix_start"]), ptr(self.vox_tabs[2]),
+                        ptr(self.vox_tabs[3]), ptr(ws["ovf_list"]), ptr(ws["counters"]), N, B, g.W, g.H, L.nx, L.ny,
+                        ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), st)
                 boi = ws["bev"]
             else:
                 Lp = levels[lv - 1]
@@ -176,7 +180,7 @@ class NativeBackbone:
                      ptr(Lp.node_slot_in), ptr(ws["counters"]), st)
                 boi = Lp.nbatch
             self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(boi),
-                 L.nx, L.ny, B, L.C, mean, 1 if lv == 0 else 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
+                 L.nx, L.ny, B, L.C, 2 if lv == 0 else mean, 1 if lv == 0 else 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
                  ptr(ws["scan_tmp"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
                  ptr(L.slot2node), ptr(L.n_dev), st)
             if lv == 0:

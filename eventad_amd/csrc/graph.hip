@@ -304,7 +304,10 @@ __global__ void k_gather_sorted(const int* __restrict__ sid, const int* __restri
                                 const float* __restrict__ pos, const float* __restrict__ pol,
                                 const float* __restrict__ map0 /* NHWC [B,h,w,16] */, int h_in, int w_in,
                                 int N, int W, int H, int* __restrict__ key_s, int* __restrict__ ts_s,
-                                float* __restrict__ posn_s, float* __restrict__ x0s) {
+                                float* __restrict__ posn_s, float* __restrict__ x0s,
+                                float vsx, float vsy, int nx, int ny, int S, const int* __restrict__ px_to_cx,
+                                const int* __restrict__ py_to_cy, int* __restrict__ node_slot, int* __restrict__ ovf_list,
+                                unsigned* __restrict__ counters) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
     int i = sid[r];
@@ -313,6 +316,18 @@ __global__ void k_gather_sorted(const int* __restrict__ sid, const int* __restri
     float px = pos[3 * i], py = pos[3 * i + 1], pt = pos[3 * i + 2];
     posn_s[3 * r] = px; posn_s[3 * r + 1] = py; posn_s[3 * r + 2] = pt;
     int b = k / (W * H);
+    if (node_slot) {
+        // pool1 voxel slot of this event, exactly as grid_cluster computes it from the float position
+        // (pooling.py:55-56); events whose slot is not the one of their pixel (t == time_window, or a
+        // position off the pixel grid) go to a side list the segmented pool kernel scans.
+        int cx = (int)__fdiv_rn(px, vsx), cy = (int)__fdiv_rn(py, vsy), ct = (int)pt;
+        long long sl = (long long)cx + (long long)nx * cy + (long long)nx * ny * (b + ct);
+        if (sl < 0 || sl >= S) { atomicOr(counters, EVAD_FLAG_POOL_WINDOW); sl = sl < 0 ? 0 : S - 1; }
+        int xi = k % W, yi = (k / W) % H;
+        int tab = px_to_cx[xi] + nx * py_to_cy[yi] + nx * ny * b;
+        node_slot[r] = (int)sl;
+        if ((int)sl != tab) ovf_list[atomicAdd(counters + 2, 1u)] = r;
+    }
     int x0, y0; float fx, fy;
     bilinear_setup(px, py, (float)W, (float)H, w_in, h_in, &x0, &y0, &fx, &fy);
     float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
@@ -347,7 +362,9 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
                                    int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
                                    uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid, int32_t* long_list,
                                    uint32_t* counters /* [0]=flags [1]=long_count */,
-                                   int32_t* key_s, int32_t* ts_s, float* posn_s, float* x0s, void* stream) {
+                                   int32_t* key_s, int32_t* ts_s, float* posn_s, float* x0s,
+                                   float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
+                                   int32_t* node_slot, int32_t* ovf_list, void* stream) {
     if (!pos || !batch || !polarity || !map0_nhwc || !key || !tq || !bev || !pix_count || !pix_start || !scan_tmp ||
         !sid_tmp || !sid || !long_list || !counters || !key_s || !ts_s || !posn_s || !x0s ||
         N < 0 || B <= 0 || W <= 0 || H <= 0 || T <= 0 || map_h <= 0 || map_w <= 0)
@@ -356,7 +373,8 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     long long P = (long long)B * H * W;
     if (P >= (1ll << 31)) return EVAD_ERR_ARG;
     hipMemsetAsync(pix_count, 0, sizeof(uint32_t) * (P + 1), st);
-    hipMemsetAsync(counters + 1, 0, sizeof(uint32_t), st);
+    hipMemsetAsync(counters + 1, 0, 2 * sizeof(uint32_t), st);
+    if (node_slot && (!px_to_cx || !py_to_cy || !ovf_list || nx <= 0 || ny <= 0 || vsx <= 0 || vsy <= 0)) return EVAD_ERR_ARG;
     if (N > 0)
         hipLaunchKernelGGL(k_prep_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, pos, (const long long*)batch, N, B,
                            W, H, T, key, tq, bev, pix_count, counters);
@@ -368,7 +386,8 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
                        long_list, counters + 1);
     hipLaunchKernelGGL(k_order_long, dim3(512), dim3(256), 0, st, pix_start, sid_tmp, sid, long_list, counters + 1);
     hipLaunchKernelGGL(k_gather_sorted, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid, key, tq, pos, polarity,
-                       map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, posn_s, x0s);
+                       map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, posn_s, x0s, vsx, vsy, nx, ny, nx * ny * (B + 1),
+                       px_to_cx, py_to_cy, node_slot, ovf_list, counters);
     return evad_last_error();
 }
 

@@ -116,6 +116,91 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
     return evad_last_error();
 }
 
+
+// --------------------------------------------------------------------------- level 0 without atomics
+// One wave per voxel slot; 4 groups of 16 lanes process 4 member events at a time (lane q of a group:
+// sampled channels 4q..4q+3 as one float4 per bilinear corner + channel q of the layer-1 output), then
+// a fixed shuffle tree merges the groups.  Max is exact and order independent; integer pixel sums too.
+__global__ __launch_bounds__(256) void k_pool_seg0(
+    const float* __restrict__ y2, const float* __restrict__ map, int map_h, int map_w, const float* __restrict__ posn_s,
+    const int* __restrict__ key_s, const int* __restrict__ sid, const int* __restrict__ node_slot,
+    const unsigned* __restrict__ pix_start, const int* __restrict__ vx_lo, const int* __restrict__ vy_lo,
+    const int* __restrict__ ovf_list, const unsigned* __restrict__ counters, int B, int W, int H, int nx, int ny, int S,
+    float* __restrict__ feat, unsigned long long* __restrict__ sums, float* __restrict__ tsum, unsigned* __restrict__ cnt,
+    int* __restrict__ maxidx) {
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= S) return;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
+    const int plane = slot / (nx * ny), rem = slot % (nx * ny), cy = rem / nx, cx = rem % nx;
+    const float NEG = -__builtin_inff();
+    float4 mx = make_float4(NEG, NEG, NEG, NEG);
+    float my = NEG, ts = 0.f;
+    unsigned n = 0; unsigned long long sx = 0, sy = 0; int mi = -1;
+    auto member = [&](int r) {
+        if (node_slot[r] != slot) return;
+        float px = posn_s[3 * r], py = posn_s[3 * r + 1];
+        int k = key_s[r];
+        int b = k / (W * H);
+        int x0, y0; float fx, fy;
+        bilin_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+        float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
+        bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
+        const float* p00 = map + (((size_t)b * map_h + y0) * map_w + x0) * 64 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto add = [&](bool ok, const float* p, float w) {
+            if (!ok) return;
+            float4 c = *(const float4*)p;
+            v.x += c.x * w; v.y += c.y * w; v.z += c.z * w; v.w += c.w * w;
+        };
+        add(vx0 && vy0, p00, w00); add(vx1 && vy0, p00 + 64, w01);
+        add(vx0 && vy1, p00 + (size_t)map_w * 64, w10); add(vx1 && vy1, p00 + (size_t)map_w * 64 + 64, w11);
+        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+        my = fmaxf(my, y2[(size_t)r * 16 + q]);
+        if (q == 0) { ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H); ts += posn_s[3 * r + 2]; mi = max(mi, sid[r]); }
+    };
+    if (plane < B) {
+        const int x0 = vx_lo[cx], x1 = vx_lo[cx + 1], y0 = vy_lo[cy], y1 = vy_lo[cy + 1];
+        for (int py = y0; py < y1; ++py) {
+            int base = W * (py + H * plane);
+            int ra = (int)pix_start[base + x0], rb = (int)pix_start[base + x1];   // a voxel row is contiguous in sorted order
+            for (int r = ra + grp; r < rb; r += 4) member(r);
+        }
+    }
+    const int n_ovf = (int)counters[2];
+    for (int i = grp; i < n_ovf; i += 4) member(ovf_list[i]);
+#pragma unroll
+    for (int d = 16; d <= 32; d <<= 1) {
+        mx.x = fmaxf(mx.x, __shfl_xor(mx.x, d, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, d, 64));
+        mx.z = fmaxf(mx.z, __shfl_xor(mx.z, d, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, d, 64));
+        my = fmaxf(my, __shfl_xor(my, d, 64));
+        n += __shfl_xor(n, d, 64); sx += __shfl_xor(sx, d, 64); sy += __shfl_xor(sy, d, 64);
+        ts += __shfl_xor(ts, d, 64); mi = max(mi, __shfl_xor(mi, d, 64));
+    }
+    if (grp == 0) {
+        float* f = feat + (size_t)slot * 80;
+        f[q] = my;
+        *(float4*)(f + 16 + 4 * q) = mx;
+        if (q == 0) { cnt[slot] = n; sums[2 * (size_t)slot] = sx; sums[2 * (size_t)slot + 1] = sy; tsum[slot] = ts; maxidx[slot] = mi; }
+    }
+}
+
+extern "C" int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
+                                 const int32_t* key_s, const int32_t* sid, const int32_t* node_slot,
+                                 const uint32_t* pix_start, const int32_t* vx_lo, const int32_t* vy_lo,
+                                 const int32_t* ovf_list, const uint32_t* counters, int N, int B, int W, int H, int nx,
+                                 int ny, float* feat, uint64_t* sums, float* tsum, uint32_t* cnt, int32_t* maxidx,
+                                 void* stream) {
+    if (!y2 || !map_nhwc || !posn_s || !key_s || !sid || !node_slot || !pix_start || !vx_lo || !vy_lo || !ovf_list ||
+        !counters || !feat || !sums || !tsum || !cnt || !maxidx || N < 0 || B <= 0 || nx <= 0 || ny <= 0)
+        return EVAD_ERR_ARG;
+    int S = nx * ny * (B + 1);
+    hipLaunchKernelGGL(k_pool_seg0, dim3(evad_blocks(S, 4)), dim3(256), 0, (hipStream_t)stream, y2, map_nhwc, map_h, map_w,
+                       posn_s, key_s, sid, node_slot, pix_start, vx_lo, vy_lo, ovf_list, counters, B, W, H, nx, ny, S, feat,
+                       (unsigned long long*)sums, tsum, cnt, maxidx);
+    return evad_last_error();
+}
+
 // --------------------------------------------------------------------------- finalize
 int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, hipStream_t st);
 
@@ -154,7 +239,7 @@ __global__ void k_finalize_nodes(const unsigned* __restrict__ occ_scan, const un
     for (int k = C + 2; k < ldx; ++k) xout[(size_t)j * ldx + k] = 0.f;
 }
 
-template <bool MEAN>
+template <int MODE>      // 0: ordered-uint max, 1: float sum -> mean, 2: float max
 __global__ void k_finalize_feat(const unsigned* __restrict__ feat, const unsigned* __restrict__ cnt,
                                 const int* __restrict__ slot2node, int S, int C, int ldx, float* __restrict__ xout) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,13 +247,13 @@ __global__ void k_finalize_feat(const unsigned* __restrict__ feat, const unsigne
     int s = (int)(t / C), c = (int)(t % C);
     int j = slot2node[s];
     if (j < 0) return;
-    float v = MEAN ? __fdiv_rn(__uint_as_float(feat[t]), (float)cnt[s]) : evad_ord2f(feat[t]);
+    float v = MODE == 1 ? __fdiv_rn(__uint_as_float(feat[t]), (float)cnt[s]) : (MODE == 2 ? __uint_as_float(feat[t]) : evad_ord2f(feat[t]));
     xout[(size_t)j * ldx + c] = v;
 }
 
 extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const float* tsum, const uint32_t* cnt,
                                      const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
-                                     int mean_aggr, int level0, int W, int H, float wh_inv_x, float wh_inv_y,
+                                     int feat_mode, int level0, int W, int H, float wh_inv_x, float wh_inv_y,
                                      uint32_t* occ_scan, uint32_t* scan_tmp, float* xout, int ldx, float* npos_out,
                                      int32_t* npix_out, int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node,
                                      int32_t* n_out_dev, void* stream) {
@@ -184,8 +269,9 @@ extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums,
                        (const unsigned long long*)sums, tsum, maxidx, batch_of_index, S, level0, (float)W, (float)H,
                        wh_inv_x, wh_inv_y, C, ldx, xout, npos_out, npix_out, nbatch_out, node_slot_out, slot2node, n_out_dev);
     dim3 grid(evad_blocks((long long)S * C, 256));
-    if (mean_aggr) hipLaunchKernelGGL(k_finalize_feat<true>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
-    else           hipLaunchKernelGGL(k_finalize_feat<false>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
+    if (feat_mode == 1)      hipLaunchKernelGGL(k_finalize_feat<1>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
+    else if (feat_mode == 2) hipLaunchKernelGGL(k_finalize_feat<2>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
+    else                     hipLaunchKernelGGL(k_finalize_feat<0>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
     return evad_last_error();
 }
 

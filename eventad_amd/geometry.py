@@ -39,6 +39,18 @@ class Geometry:
             # pooled-edge bitmap window is 5x5 voxels: radius graph edges must stay within 2 voxels
             assert math.ceil(self.radius_px / (vx * width)) <= 2 and math.ceil(self.radius_px / (vy * height)) <= 2
 
+    def pixel_voxel_tables(self):
+        """pool1: voxel column/row of every pixel as grid_cluster computes it ((px/W)/vx truncated, fp32),
+        and the first pixel of every voxel column/row (+ sentinel)."""
+        vx, vy = self.voxel[0]
+        nx, ny = self.grid[0]
+        cx = ((torch.arange(self.W).float() / float(self.W)) / torch.tensor(vx)).long()
+        cy = ((torch.arange(self.H).float() / float(self.H)) / torch.tensor(vy)).long()
+        assert int(cx.max()) < nx and int(cy.max()) < ny and bool((cx[1:] >= cx[:-1]).all()) and bool((cy[1:] >= cy[:-1]).all())
+        lo_x = torch.searchsorted(cx, torch.arange(nx + 1)).int()
+        lo_y = torch.searchsorted(cy, torch.arange(ny + 1)).int()
+        return cx.int(), cy.int(), lo_x, lo_y
+
     def max_nodes(self, level, B):
         nx, ny = self.grid[level]
         return nx * ny * (B + 1)

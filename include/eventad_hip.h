@@ -55,12 +55,16 @@ int eventad_spiral_offsets(int radius, int16_t* dxdy);
  *   out: key/tq/bev i32[N] (event order: pixel key, t in us, clip), pix_start u32[B*H*W+1],
  *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], posn_s f32[N,3], x0s f32[N,20]
  *   ws : pix_count u32[B*H*W+1], scan_tmp u32[B*H*W/2048+2], sid_tmp i32[N], long_list i32[B*H*W],
- *        counters u32[4] ([0] = EVENTAD_FLAG_* bits, caller zeroes it; [1] internal) */
+ *        counters u32[4] ([0] = EVENTAD_FLAG_* bits, caller zeroes it; [1] internal; [2] = length of ovf_list)
+ *   pool1 prep (node_slot nullable = skip): node_slot i32[N] = voxel slot of each sorted event computed from its
+ *        float position as grid_cluster does (pooling.py:55-56); px_to_cx i32[W] / py_to_cy i32[H] = voxel of a
+ *        pixel; events whose slot differs from their pixel's (t == time_window, off-grid positions) -> ovf_list */
 int eventad_sort_events(const float* pos, const int64_t* batch, const float* polarity, const float* map0_nhwc,
                         int map_h, int map_w, int N, int B, int W, int H, int T, int32_t* key, int32_t* tq,
                         int32_t* bev, uint32_t* pix_count, uint32_t* pix_start, uint32_t* scan_tmp, int32_t* sid_tmp,
                         int32_t* sid, int32_t* long_list, uint32_t* counters, int32_t* key_s, int32_t* ts_s,
-                        float* posn_s, float* x0s, void* stream);
+                        float* posn_s, float* x0s, float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx,
+                        const int32_t* py_to_cy, int32_t* node_slot, int32_t* ovf_list, void* stream);
 /* eventad_build_ell: the edge search of ev_graph.cu:15-80 over the pixel CSR.  ELL adjacency in
  * pixel-sorted numbering: ell_src i32[N,K] (slot 0 = self edge), ell_step u16[N,K] (spiral step =
  * LUT cell of the source pixel), deg i32[N]. */
@@ -94,9 +98,18 @@ int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc
                          const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx, float vsy,
                          int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums, float* tsum,
                          uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, void* stream);
+/* Level-0 pooling without atomics: one wave per voxel slot walks the slot's pixel rows in the pixel CSR
+ * (events of a voxel row are contiguous in sorted order), samples the 64-channel CNN map per member and
+ * keeps running maxima in registers.  vx_lo i32[nx+1] / vy_lo i32[ny+1] = first pixel of each voxel column
+ * / row.  Writes feat f32[S,80] (plain floats: finalize mode 2), sums, tsum, cnt, maxidx for EVERY slot. */
+int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
+                      const int32_t* key_s, const int32_t* sid, const int32_t* node_slot, const uint32_t* pix_start,
+                      const int32_t* vx_lo, const int32_t* vy_lo, const int32_t* ovf_list, const uint32_t* counters,
+                      int N, int B, int W, int H, int nx, int ny, float* feat, uint64_t* sums, float* tsum,
+                      uint32_t* cnt, int32_t* maxidx, void* stream);
 int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const float* tsum, const uint32_t* cnt,
                           const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
-                          int mean_aggr, int level0, int W, int H, float wh_inv_x, float wh_inv_y, uint32_t* occ_scan,
+                          int feat_mode /* 0 ordered-uint max, 1 mean, 2 float max */, int level0, int W, int H, float wh_inv_x, float wh_inv_y, uint32_t* occ_scan,
                           uint32_t* scan_tmp, float* xout, int ldx, float* npos_out, int32_t* npix_out,
                           int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node, int32_t* n_out_dev,
                           void* stream);
