@@ -34,8 +34,9 @@ __device__ __forceinline__ float4 matvec4(const float (&x)[CINP], const float* _
 
 // LUT row stride in LDS: CINP*16 floats + 16 pad so consecutive steps start 16 banks apart
 // (ds_read_b128 banks are (addr/4)%64; an unpadded CINP*16 stride is a multiple of 64 for CINP=20,16).
+#define L1_THREADS 512          // 8 waves share one LDS copy of the LUT: 2 workgroups/CU = 16 waves/CU
 template <int CINP, bool SKIP, bool LUT_IN_LDS>
-__global__ __launch_bounds__(256) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
+__global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
                                                  const uint16_t* __restrict__ ell_step, const int* __restrict__ deg,
                                                  const float* __restrict__ lut, const float* __restrict__ root,
                                                  const float* __restrict__ scale, const float* __restrict__ shift,
@@ -47,26 +48,44 @@ __global__ __launch_bounds__(256) void k_l1_conv(const float* __restrict__ xin, 
     float* s_root = smem;                                 // [CINP][16]
     float* s_skip = s_root + CINP * 16;                   // [20][16] (SKIP only)
     float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [steps][LS]
-    for (int t = threadIdx.x; t < CINP * 16; t += 256) s_root[t] = root[t];
-    if (SKIP) for (int t = threadIdx.x; t < 20 * 16; t += 256) s_skip[t] = wskip[t];
+    for (int t = threadIdx.x; t < CINP * 16; t += L1_THREADS) s_root[t] = root[t];
+    if (SKIP) for (int t = threadIdx.x; t < 20 * 16; t += L1_THREADS) s_skip[t] = wskip[t];
     if (LUT_IN_LDS)
-        for (int t = threadIdx.x; t < steps * CINP * 16; t += 256) s_lut[(t / (CINP * 16)) * LS + t % (CINP * 16)] = lut[t];
+        for (int t = threadIdx.x; t < steps * CINP * 16; t += L1_THREADS) s_lut[(t / (CINP * 16)) * LS + t % (CINP * 16)] = lut[t];
     __syncthreads();
 
     const int l4 = (threadIdx.x & 3) * 4;
-    const int node = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int node = blockIdx.x * (L1_THREADS / 4) + (threadIdx.x >> 2);
     if (node >= N) return;
     const int d = deg[node];
-    const int* srcs = ell_src + (size_t)node * max_nb;
-    const uint16_t* stp = ell_step + (size_t)node * max_nb;
+    // the whole ELL row up front (16 sources = 64 B, 16 cells = 32 B): the neighbour gathers below no
+    // longer wait on an index load, and the next neighbour's row is fetched while this one is multiplied
+    int src[16]; int cell[16];
+    {
+        const int4* sp = (const int4*)(ell_src + (size_t)node * 16);
+        const uint4* cp = (const uint4*)(ell_step + (size_t)node * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int4 v = sp[q]; src[4 * q] = v.x; src[4 * q + 1] = v.y; src[4 * q + 2] = v.z; src[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint4 v = cp[q];
+            cell[8 * q] = v.x & 0xffff; cell[8 * q + 1] = v.x >> 16; cell[8 * q + 2] = v.y & 0xffff; cell[8 * q + 3] = v.y >> 16;
+            cell[8 * q + 4] = v.z & 0xffff; cell[8 * q + 5] = v.z >> 16; cell[8 * q + 6] = v.w & 0xffff; cell[8 * q + 7] = v.w >> 16;
+        }
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float x[CINP];
-    for (int e = 0; e < d; ++e) {
-        int s = srcs[e], c = stp[e];
-        load_row<CINP>(xin + (size_t)s * CINP, x);
-        float4 m = LUT_IN_LDS ? matvec4<CINP>(x, s_lut + c * LS + l4)
-                              : matvec4<CINP>(x, lut + (size_t)c * CINP * 16 + l4);
-        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    float x[CINP], xn[CINP];
+    load_row<CINP>(xin + (size_t)node * CINP, xn);         // slot 0 is the self edge: src[0] == node
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (e < d) {
+#pragma unroll
+            for (int k = 0; k < CINP; ++k) x[k] = xn[k];
+            if (e + 1 < 16 && e + 1 < d) load_row<CINP>(xin + (size_t)src[e + 1 < 16 ? e + 1 : 15] * CINP, xn);
+            float4 m = LUT_IN_LDS ? matvec4<CINP>(x, s_lut + cell[e] * LS + l4)
+                                  : matvec4<CINP>(x, lut + (size_t)cell[e] * CINP * 16 + l4);
+            acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+        }
     }
     load_row<CINP>(xin + (size_t)node * CINP, x);
     float4 m = matvec4<CINP>(x, s_root + l4);                                 // root weight (spline_conv.py:72-73)
@@ -91,7 +110,8 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     constexpr int LS = CINP * 16 + 16;
     size_t fixed = sizeof(float) * (CINP * 16 + (SKIP ? 320 : 0));
     size_t with_lut = fixed + sizeof(float) * (size_t)steps * LS;
-    dim3 grid(evad_blocks(N, 64)), block(256);
+    if (max_nb != 16) return EVAD_ERR_ARG;              // the ELL row is read as 4 x int4 + 2 x uint4
+    dim3 grid(evad_blocks(N, L1_THREADS / 4)), block(L1_THREADS);
     if (with_lut <= 80 * 1024) {            // two workgroups per CU (160 KiB LDS)
         auto kern = k_l1_conv<CINP, SKIP, true>;
         static size_t attr_set = 0;                 // raise the dynamic-LDS limit once per size (not a stream op)
