@@ -32,6 +32,8 @@ class NativeBackbone:
         self.device = torch.device(device)
         self.prefix = prefix
         self._ws_key = None
+        self.fused_mark = False        # measured on C2: reference-style search 141 us + separate marking 98 us beats the
+                                       # batched search with fused marking (222 us); see tools/microbench_ell.py
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
 
@@ -80,9 +82,9 @@ class NativeBackbone:
             counters=torch.zeros(4, dtype=torch.int32, device=dev),
             key=i32(N), tq=i32(N), bev=i32(N), pix_count=i32(P + 1), pix_start=i32(P + 1),
             scan_tmp=i32(max(P, 1 << 16) // 2048 + 4), sid_tmp=i32(N), sid=i32(N), long_list=i32(P),
-            key_s=i32(N), ts_s=i32(N), posn_s=f32(N, 3), x0s=f32(N, 20),
+            key_s=i32(N), ts_s=i32(N), ev2=i32(N, 2), posn_s=f32(N, 3), x0s=f32(N, 20),
             ell_src=i32(N, K), ell_step=torch.empty((N, K), dtype=torch.int16, device=dev), deg=i32(N),
-            y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N), ovf_list=i32(max(N, 1)),
+            y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N), node_vox0=i32(N), ovf_list=i32(max(N, 1)),
         )
         levels = []
         for lv in range(4):
@@ -148,11 +150,13 @@ class NativeBackbone:
         self._c("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
              N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
              ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["long_list"]), ptr(ws["counters"]),
-             ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
+             ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
-             ptr(ws["ovf_list"]), st)
-        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
-             N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), st)
+             ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), st)
+        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if self.fused_mark else None, ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
+             N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
+             ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],
+             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, st)
         self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
              ptr(w["root1"]), ptr(w["bn1"][0]), ptr(w["bn1"][1]), ptr(ws["y1"]), N, g.steps, K, st)
         self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
@@ -183,7 +187,9 @@ class NativeBackbone:
                  L.nx, L.ny, B, L.C, 2 if lv == 0 else mean, 1 if lv == 0 else 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
                  ptr(ws["scan_tmp"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
                  ptr(L.slot2node), ptr(L.n_dev), st)
-            if lv == 0:
+            if lv == 0 and self.fused_mark:
+                pass
+            elif lv == 0:
                 self._c("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
                      L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
             else:

@@ -30,3 +30,27 @@ __device__ __forceinline__ unsigned evad_f2ord(float f) {
 __device__ __forceinline__ float evad_ord2f(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
+
+// Pooled-edge dedup (pool.hip): bit index of a source slot relative to its destination slot in the
+// destination's 5x5x3 neighbour-window bitmap: ((dp+1)*5 + (dy+2))*5 + (dx+2).
+__device__ __forceinline__ void evad_mark_edge(int ss, int sd, int nx, int ny, unsigned* __restrict__ bitmap, unsigned* flags) {
+    if (ss == sd) return;                                   // self loop after clustering: dropped (pooling.py:62-64)
+    int plane = nx * ny;
+    int dx = ss % nx - sd % nx, dy = (ss / nx) % ny - (sd / nx) % ny, dp = ss / plane - sd / plane;
+    if (dx < -2 || dx > 2 || dy < -2 || dy > 2 || dp < -1 || dp > 1) { atomicOr(flags, EVAD_FLAG_POOL_WINDOW); return; }
+    int bit = ((dp + 1) * 5 + (dy + 2)) * 5 + (dx + 2);
+    unsigned* w = bitmap + (size_t)sd * 3 + (bit >> 5);
+    unsigned m = 1u << (bit & 31);
+    if (!(*(volatile unsigned*)w & m)) atomicOr(w, m);
+}
+
+// same with pre-decomposed voxel coordinates packed as cx | cy << 8 | plane << 16 (no integer divisions)
+__device__ __forceinline__ void evad_mark_edge_packed(int vs, int vd, int slot_d, unsigned* __restrict__ bitmap, unsigned* flags) {
+    if (vs == vd) return;
+    int dx = (vs & 255) - (vd & 255), dy = ((vs >> 8) & 255) - ((vd >> 8) & 255), dp = (vs >> 16) - (vd >> 16);
+    if (dx < -2 || dx > 2 || dy < -2 || dy > 2 || dp < -1 || dp > 1) { atomicOr(flags, EVAD_FLAG_POOL_WINDOW); return; }
+    int bit = ((dp + 1) * 5 + (dy + 2)) * 5 + (dx + 2);
+    unsigned* w = bitmap + (size_t)slot_d * 3 + (bit >> 5);
+    unsigned m = 1u << (bit & 31);
+    if (!(*(volatile unsigned*)w & m)) atomicOr(w, m);
+}

@@ -303,16 +303,17 @@ __device__ __forceinline__ void bilinear_setup(float px_norm, float py_norm, flo
 __global__ void k_gather_sorted(const int* __restrict__ sid, const int* __restrict__ key, const int* __restrict__ tq,
                                 const float* __restrict__ pos, const float* __restrict__ pol,
                                 const float* __restrict__ map0 /* NHWC [B,h,w,16] */, int h_in, int w_in,
-                                int N, int W, int H, int* __restrict__ key_s, int* __restrict__ ts_s,
+                                int N, int W, int H, int* __restrict__ key_s, int* __restrict__ ts_s, int2* __restrict__ ev2,
                                 float* __restrict__ posn_s, float* __restrict__ x0s,
                                 float vsx, float vsy, int nx, int ny, int S, const int* __restrict__ px_to_cx,
-                                const int* __restrict__ py_to_cy, int* __restrict__ node_slot, int* __restrict__ ovf_list,
-                                unsigned* __restrict__ counters) {
+                                const int* __restrict__ py_to_cy, int* __restrict__ node_slot, int* __restrict__ node_vox,
+                                int* __restrict__ ovf_list, unsigned* __restrict__ counters) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
     int i = sid[r];
     int k = key[i];
     key_s[r] = k; ts_s[r] = tq[i];
+    if (ev2) ev2[r] = make_int2(i, tq[i]);
     float px = pos[3 * i], py = pos[3 * i + 1], pt = pos[3 * i + 2];
     posn_s[3 * r] = px; posn_s[3 * r + 1] = py; posn_s[3 * r + 2] = pt;
     int b = k / (W * H);
@@ -326,6 +327,7 @@ __global__ void k_gather_sorted(const int* __restrict__ sid, const int* __restri
         int xi = k % W, yi = (k / W) % H;
         int tab = px_to_cx[xi] + nx * py_to_cy[yi] + nx * ny * b;
         node_slot[r] = (int)sl;
+        { int pl = (int)(sl / (nx * ny)), rm = (int)(sl % (nx * ny)); node_vox[r] = (rm % nx) | ((rm / nx) << 8) | (pl << 16); }
         if ((int)sl != tab) ovf_list[atomicAdd(counters + 2, 1u)] = r;
     }
     int x0, y0; float fx, fy;
@@ -362,9 +364,9 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
                                    int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
                                    uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid, int32_t* long_list,
                                    uint32_t* counters /* [0]=flags [1]=long_count */,
-                                   int32_t* key_s, int32_t* ts_s, float* posn_s, float* x0s,
+                                   int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s,
                                    float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
-                                   int32_t* node_slot, int32_t* ovf_list, void* stream) {
+                                   int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, void* stream) {
     if (!pos || !batch || !polarity || !map0_nhwc || !key || !tq || !bev || !pix_count || !pix_start || !scan_tmp ||
         !sid_tmp || !sid || !long_list || !counters || !key_s || !ts_s || !posn_s || !x0s ||
         N < 0 || B <= 0 || W <= 0 || H <= 0 || T <= 0 || map_h <= 0 || map_w <= 0)
@@ -374,7 +376,7 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     if (P >= (1ll << 31)) return EVAD_ERR_ARG;
     hipMemsetAsync(pix_count, 0, sizeof(uint32_t) * (P + 1), st);
     hipMemsetAsync(counters + 1, 0, 2 * sizeof(uint32_t), st);
-    if (node_slot && (!px_to_cx || !py_to_cy || !ovf_list || nx <= 0 || ny <= 0 || vsx <= 0 || vsy <= 0)) return EVAD_ERR_ARG;
+    if (node_slot && (!px_to_cx || !py_to_cy || !ovf_list || !node_vox || nx <= 0 || ny <= 0 || vsx <= 0 || vsy <= 0)) return EVAD_ERR_ARG;
     if (N > 0)
         hipLaunchKernelGGL(k_prep_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, pos, (const long long*)batch, N, B,
                            W, H, T, key, tq, bev, pix_count, counters);
@@ -386,8 +388,8 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
                        long_list, counters + 1);
     hipLaunchKernelGGL(k_order_long, dim3(512), dim3(256), 0, st, pix_start, sid_tmp, sid, long_list, counters + 1);
     hipLaunchKernelGGL(k_gather_sorted, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid, key, tq, pos, polarity,
-                       map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, posn_s, x0s, vsx, vsy, nx, ny, nx * ny * (B + 1),
-                       px_to_cx, py_to_cy, node_slot, ovf_list, counters);
+                       map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, (int2*)ev2, posn_s, x0s, vsx, vsy, nx, ny, nx * ny * (B + 1),
+                       px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, counters);
     return evad_last_error();
 }
 
@@ -430,20 +432,113 @@ __global__ __launch_bounds__(256) void k_build_ell(const int* __restrict__ sid, 
     deg[r] = nn;
 }
 
-extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* key_s, const uint32_t* pix_start,
-                                 const uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
+// The edge search is bound by dependent memory round trips, not bytes: per spiral step the reference
+// kernel loads the FIFO head, then id, then timestamp, one after the other.  Here a thread fetches the
+// pixel-CSR offsets of 8 spiral steps together (16 independent loads), then the newest entry of each of
+// those 8 segments together (8 independent 8-byte {id, t} loads); only deeper entries of a segment are
+// dependent loads.  ~3 round trips per 8 steps instead of ~24.  Afterwards the emitted edges set their
+// source-voxel bit in the destination voxel's pool1 neighbour bitmap (replaces a second pass over the
+// ELL, pool.hip k_mark_ell); voxel coordinates come pre-decomposed so no integer division is needed.
+#define ELL_GROUP 8
+__global__ __launch_bounds__(256) void k_build_ell_g(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+                                                     const unsigned* __restrict__ start, const int16_t* __restrict__ spiral,
+                                                     const unsigned* flags_in, int N, int W, int H, int steps, int Q, int dt_max,
+                                                     int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
+                                                     int* __restrict__ deg, const int* __restrict__ node_slot,
+                                                     const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
+                                                     unsigned* flags) {
+    constexpr int MAXNB = 16;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
+    const int k = key_s[r];
+    const int2 mine = ev2[r];
+    const int me = mine.x, ts = mine.y;
+    const int x = k % W, y = (k / W) % H, plane_base = k - x - W * y;
+    int nb[MAXNB]; int stp[MAXNB];
+#pragma unroll
+    for (int e = 0; e < MAXNB; ++e) { nb[e] = 0; stp[e] = 0; }
+    nb[0] = r;
+    int nn = 1;
+    auto emit = [&](int s, int i) {                           // static indexing keeps nb/stp in registers
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) if (e == nn) { nb[e] = s; stp[e] = i; }
+        ++nn;
+    };
+    for (int i0 = 0; i0 < steps && nn < MAXNB; i0 += ELL_GROUP) {
+        int st[ELL_GROUP], en[ELL_GROUP];
+#pragma unroll
+        for (int u = 0; u < ELL_GROUP; ++u) {
+            st[u] = 0; en[u] = 0;
+            int i = i0 + u;
+            if (i < steps) {
+                int xn = x + spiral[2 * i], yn = y + spiral[2 * i + 1];
+                if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
+                    int p = plane_base + xn + W * yn;
+                    st[u] = (int)start[p]; en[u] = (int)start[p + 1];
+                }
+            }
+        }
+        int2 head[ELL_GROUP];
+#pragma unroll
+        for (int u = 0; u < ELL_GROUP; ++u) head[u] = en[u] > st[u] ? ev2[en[u] - 1] : make_int2(0, 0);
+#pragma unroll
+        for (int u = 0; u < ELL_GROUP; ++u) {
+            if (nn < MAXNB) {
+                const int lo = max(st[u], en[u] - Q);
+                for (int s = en[u] - 1; s >= lo; --s) {
+                    int2 c = (s == en[u] - 1) ? head[u] : ev2[s];
+                    if (me > c.x) {
+                        if ((float)(ts - c.y) > (float)dt_max) { if (monotone) break; else continue; }
+                        emit(s, i0 + u);
+                        if (nn >= MAXNB) break;
+                    }
+                }
+            }
+        }
+    }
+    // ELL row: 64 B of sources + 32 B of steps, written as whole vectors
+    int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
+    rp[0] = make_int4(nb[0], nb[1], nb[2], nb[3]); rp[1] = make_int4(nb[4], nb[5], nb[6], nb[7]);
+    rp[2] = make_int4(nb[8], nb[9], nb[10], nb[11]); rp[3] = make_int4(nb[12], nb[13], nb[14], nb[15]);
+    uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
+    sp4[0] = make_uint4(stp[0] | stp[1] << 16, stp[2] | stp[3] << 16, stp[4] | stp[5] << 16, stp[6] | stp[7] << 16);
+    sp4[1] = make_uint4(stp[8] | stp[9] << 16, stp[10] | stp[11] << 16, stp[12] | stp[13] << 16, stp[14] | stp[15] << 16);
+    deg[r] = nn;
+    if (bitmap) {
+        const int my_slot = node_slot[r], my_vox = node_vox[r];
+        int vs[MAXNB];
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[nb[e]] : my_vox;      // independent gathers
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
+    }
+}
+
+extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
+                                 const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
-                                 int32_t* deg, void* stream) {
+                                 int32_t* deg, const int32_t* node_slot, const int32_t* node_vox, int nx, int ny,
+                                 uint32_t* bitmap, void* stream) {
     if (!sid || !ts_s || !key_s || !pix_start || !counters || !ell_src || !ell_step || !deg || N < 0 || B <= 0 ||
-        W <= 0 || H <= 0 || radius_px < 0 || max_num_neighbors < 1 || max_num_neighbors > 65535 || queue_size < 1)
+        W <= 0 || H <= 0 || radius_px < 0 || max_num_neighbors < 1 || max_num_neighbors > 65535 || queue_size < 1 ||
+        (bitmap && (!node_slot || !node_vox || nx <= 0 || ny <= 0 || nx > 255 || ny > 255)))
         return EVAD_ERR_ARG;
-    if (N == 0) return EVAD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (bitmap) hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    if (N == 0) return evad_last_error();
     int steps;
-    if (ensure_spiral(radius_px, (hipStream_t)stream, &steps)) return -2;
+    if (ensure_spiral(radius_px, st, &steps)) return -2;
     if (steps > 65535) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_build_ell, dim3(evad_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, sid, ts_s, key_s,
-                       pix_start, g_spiral_dev, counters, N, W, H, steps, queue_size, delta_t_us, max_num_neighbors,
-                       ell_src, ell_step, deg);
+    if (max_num_neighbors == 16 && ev2)
+        hipLaunchKernelGGL(k_build_ell_g, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
+                           g_spiral_dev, counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
+                           node_vox, bitmap, counters);
+    else {
+        if (bitmap) return EVAD_ERR_ARG;                     // fused marking only exists in the batched kernel
+        hipLaunchKernelGGL(k_build_ell, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid, ts_s, key_s, pix_start, g_spiral_dev,
+                           counters, N, W, H, steps, queue_size, delta_t_us, max_num_neighbors, ell_src, ell_step, deg);
+    }
     return evad_last_error();
 }
 

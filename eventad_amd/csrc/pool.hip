@@ -276,25 +276,13 @@ extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums,
 }
 
 // --------------------------------------------------------------------------- pooled edges
-// bit index of a source slot relative to its destination slot: ((dp+1)*5 + (dy+2))*5 + (dx+2)
-__device__ __forceinline__ void mark_edge(int ss, int sd, int nx, int ny, unsigned* __restrict__ bitmap, unsigned* flags) {
-    if (ss == sd) return;                                   // self loop after clustering: dropped (pooling.py:62-64)
-    int plane = nx * ny;
-    int dx = ss % nx - sd % nx, dy = (ss / nx) % ny - (sd / nx) % ny, dp = ss / plane - sd / plane;
-    if (dx < -2 || dx > 2 || dy < -2 || dy > 2 || dp < -1 || dp > 1) { atomicOr(flags, EVAD_FLAG_POOL_WINDOW); return; }
-    int bit = ((dp + 1) * 5 + (dy + 2)) * 5 + (dx + 2);
-    unsigned* w = bitmap + (size_t)sd * 3 + (bit >> 5);
-    unsigned m = 1u << (bit & 31);
-    if (!(*(volatile unsigned*)w & m)) atomicOr(w, m);
-}
-
 __global__ void k_mark_ell(const int* __restrict__ ell_src, const int* __restrict__ deg, const int* __restrict__ node_slot,
                            int N, int max_nb, int nx, int ny, unsigned* __restrict__ bitmap, unsigned* __restrict__ flags) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * max_nb) return;
     int r = (int)(t / max_nb), k = (int)(t % max_nb);
     if (k == 0 || k >= deg[r]) return;
-    mark_edge(node_slot[ell_src[t]], node_slot[r], nx, ny, bitmap, flags);
+    evad_mark_edge(node_slot[ell_src[t]], node_slot[r], nx, ny, bitmap, flags);
 }
 
 __global__ void k_mark_csr(const unsigned* __restrict__ rowptr, const int* __restrict__ csr_src,
@@ -305,7 +293,7 @@ __global__ void k_mark_csr(const unsigned* __restrict__ rowptr, const int* __res
     int node = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
     if (node >= n) return;
     int sd = node_slot[node];
-    for (unsigned e = rowptr[node] + lane; e < rowptr[node + 1]; e += 16) mark_edge(node_slot[csr_src[e]], sd, nx, ny, bitmap, flags);
+    for (unsigned e = rowptr[node] + lane; e < rowptr[node + 1]; e += 16) evad_mark_edge(node_slot[csr_src[e]], sd, nx, ny, bitmap, flags);
 }
 
 __global__ void k_edge_count(const unsigned* __restrict__ bitmap, const int* __restrict__ node_slot_out, int n_max,

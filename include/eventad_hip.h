@@ -53,25 +53,26 @@ int eventad_spiral_offsets(int radius, int16_t* dxdy);
  * [polarity, 16 bilinear samples of CNN map 0 (net.py:116,200-228), pos_x, pos_y, 0].
  *   in : pos f32[N,3] normalised, batch i64[N], polarity f32[N], map0 f32[B,h,w,16] (NHWC)
  *   out: key/tq/bev i32[N] (event order: pixel key, t in us, clip), pix_start u32[B*H*W+1],
- *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], posn_s f32[N,3], x0s f32[N,20]
+ *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], ev2 i32[N,2] = {id, t} pairs (nullable), posn_s f32[N,3], x0s f32[N,20]
  *   ws : pix_count u32[B*H*W+1], scan_tmp u32[B*H*W/2048+2], sid_tmp i32[N], long_list i32[B*H*W],
  *        counters u32[4] ([0] = EVENTAD_FLAG_* bits, caller zeroes it; [1] internal; [2] = length of ovf_list)
  *   pool1 prep (node_slot nullable = skip): node_slot i32[N] = voxel slot of each sorted event computed from its
  *        float position as grid_cluster does (pooling.py:55-56); px_to_cx i32[W] / py_to_cy i32[H] = voxel of a
- *        pixel; events whose slot differs from their pixel's (t == time_window, off-grid positions) -> ovf_list */
+ *        pixel; node_vox i32[N] = the slot decomposed as cx | cy<<8 | plane<<16; events whose slot differs from their pixel's (t == time_window, off-grid positions) -> ovf_list */
 int eventad_sort_events(const float* pos, const int64_t* batch, const float* polarity, const float* map0_nhwc,
                         int map_h, int map_w, int N, int B, int W, int H, int T, int32_t* key, int32_t* tq,
                         int32_t* bev, uint32_t* pix_count, uint32_t* pix_start, uint32_t* scan_tmp, int32_t* sid_tmp,
-                        int32_t* sid, int32_t* long_list, uint32_t* counters, int32_t* key_s, int32_t* ts_s,
+                        int32_t* sid, int32_t* long_list, uint32_t* counters, int32_t* key_s, int32_t* ts_s, int32_t* ev2,
                         float* posn_s, float* x0s, float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx,
-                        const int32_t* py_to_cy, int32_t* node_slot, int32_t* ovf_list, void* stream);
+                        const int32_t* py_to_cy, int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, void* stream);
 /* eventad_build_ell: the edge search of ev_graph.cu:15-80 over the pixel CSR.  ELL adjacency in
  * pixel-sorted numbering: ell_src i32[N,K] (slot 0 = self edge), ell_step u16[N,K] (spiral step =
- * LUT cell of the source pixel), deg i32[N]. */
-int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* key_s, const uint32_t* pix_start,
-                      const uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
+ * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
+ * the source-voxel bit in the destination voxel's pool1 neighbour bitmap u32[S,3] (= eventad_pool_edges_mark_ell). */
+int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
+                      const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                       int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step, int32_t* deg,
-                      void* stream);
+                      const int32_t* node_slot, const int32_t* node_vox, int nx, int ny, uint32_t* bitmap, void* stream);
 /* ELL -> the reference's edge buffer layout (i64[2,K], event numbering, -1 padded). */
 int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32_t* sid, int N, int max_num_neighbors,
                          int64_t K, int64_t* edges, void* stream);
