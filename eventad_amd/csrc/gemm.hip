@@ -251,37 +251,49 @@ extern "C" int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int
 }
 
 // =============================================================================================
-// Grouped split-K GEMM for M <= 32 (the clip-to-clip chain of the head).
-// A [32,K]x[K,N] product has only N/64 output blocks -- 4..12 workgroups on a 256-CU chip, each
-// walking K serially (measured 15-30 us per product).  Here up to 4 independent products go out in
-// ONE launch, every workgroup is one wave that owns a 32x32 output tile and a 64-deep K chunk
-// (=> ~100 waves per product, all loads of a wave in flight at once), and the K chunks are written
-// as partial slabs part[ks][32][N].  k_m32_reduce then sums the slabs IN ORDER (bitwise reproducible,
-// no float atomics) and applies bias / accumulate.
+// Grouped split-K tile GEMM -- the head's workhorse.
+// The head's products are small ([32..768] x [4..768] x [4..768]); as single launches of a 64x64- or
+// 128x128-tiled kernel they fill 4..48 workgroups of a 256-CU chip and walk K serially (measured
+// 15-30 us each).  Here up to 8 independent products go out in ONE launch; every workgroup is one wave
+// that owns a 32x32 output tile and a 64-deep K chunk (=> 100-800 waves per launch, all 16 loads of a
+// wave in flight at once).  K chunks are written as partial slabs part[ks][M][N]; k_tile_reduce then
+// sums the slabs IN ORDER (bitwise reproducible, no float atomics) and applies bias / relu /
+// accumulate.  Products with K <= 64 skip the slab and write C directly.
 // =============================================================================================
-#define M32_MAXP 4
-struct M32Prob {
+#define TG_MAXP 8
+struct TProb {
     const float* A; const float* B; float* part; float* C; const float* bias;
-    int lda, ldb, ldc, M, N, K, tb, acc, tiles_n, ksplit, block0;
+    int lda, ldb, ldc, M, N, K, ta, tb, acc, relu, tiles_m, tiles_n, ksplit, block0;
 };
-struct M32Group { M32Prob p[M32_MAXP]; int n; };
+struct TGroup { TProb p[TG_MAXP]; int n; };
 
-__global__ __launch_bounds__(64) void k_m32_splitk(M32Group g) {
+__global__ __launch_bounds__(64) void k_tile_splitk(TGroup g) {
     __shared__ float As[64][33];
     __shared__ float Bs[64][33];
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < M32_MAXP; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].block0) pi = i;
-    const M32Prob& P = g.p[pi];
+    for (int i = 1; i < TG_MAXP; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].block0) pi = i;
+    const TProb& P = g.p[pi];
     const int local = blockIdx.x - P.block0;
-    const int nt = local % P.tiles_n, ks = local / P.tiles_n;
-    const int n0 = nt * 32, k0 = ks * 64, lane = threadIdx.x;
+    const int per_k = P.tiles_m * P.tiles_n;
+    const int ks = local / per_k, rem = local % per_k, mt = rem / P.tiles_n, nt = rem % P.tiles_n;
+    const int m0 = mt * 32, n0 = nt * 32, k0 = ks * 64, lane = threadIdx.x;
+    if (P.ta) {                                             // A stored [K,M]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {                           // A tile: 32 rows x 64 k
-        int f = lane + 64 * i, row = f >> 4, kq = (f & 15) * 4, gk = k0 + kq;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < P.M) v = ld4_guard(P.A + (size_t)row * P.lda + gk, gk, P.K);
-        As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
+        for (int i = 0; i < 8; ++i) {
+            int f = lane + 64 * i, kr = f >> 3, mq = (f & 7) * 4, gk = k0 + kr, gm = m0 + mq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < P.K) v = ld4_guard(P.A + (size_t)gk * P.lda + gm, gm, P.M);
+            As[kr][mq] = v.x; As[kr][mq + 1] = v.y; As[kr][mq + 2] = v.z; As[kr][mq + 3] = v.w;
+        }
+    } else {                                                // A stored [M,K]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int f = lane + 64 * i, row = f >> 4, kq = (f & 15) * 4, gk = k0 + kq, gm = m0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < P.M) v = ld4_guard(P.A + (size_t)gm * P.lda + gk, gk, P.K);
+            As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
+        }
     }
     if (P.tb) {                                             // B stored [N,K]
 #pragma unroll
@@ -309,56 +321,69 @@ __global__ __launch_bounds__(64) void k_m32_splitk(M32Group g) {
         int kr = kk + (lane >> 5), c = lane & 31;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kr][c], Bs[kr][c], acc, 0, 0, 0);
     }
-    float* out = P.part + (size_t)ks * 32 * P.N;
-    int gn = n0 + (lane & 31);
-    if (gn < P.N) {
+    const int gn = n0 + (lane & 31);
+    if (gn >= P.N) return;
+    if (P.ksplit == 1) {                                    // whole K in this chunk: finish here
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int gm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            out[(size_t)gm * P.N + gn] = acc[r];
+            int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gm >= P.M) continue;
+            float v = acc[r];
+            if (P.bias) v += P.bias[gn];
+            if (P.relu) v = fmaxf(v, 0.f);
+            if (P.acc) v += P.C[(size_t)gm * P.ldc + gn];
+            P.C[(size_t)gm * P.ldc + gn] = v;
+        }
+    } else {
+        float* out = P.part + (size_t)ks * P.M * P.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gm < P.M) out[(size_t)gm * P.N + gn] = acc[r];
         }
     }
 }
 
-__global__ void k_m32_reduce(M32Group g) {
+__global__ void k_tile_reduce(TGroup g) {
     int pi = blockIdx.y;
     if (pi >= g.n) return;
-    const M32Prob& P = g.p[pi];
-    if (!P.C) return;                                       // consumer sums the slabs itself
+    const TProb& P = g.p[pi];
+    if (P.ksplit == 1) return;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.M * P.N) return;
     int m = t / P.N, n = t % P.N;
     float v = 0.f;
-    for (int ks = 0; ks < P.ksplit; ++ks) v += P.part[((size_t)ks * 32 + m) * P.N + n];
+    for (int ks = 0; ks < P.ksplit; ++ks) v += P.part[((size_t)ks * P.M + m) * P.N + n];
     if (P.bias) v += P.bias[n];
+    if (P.relu) v = fmaxf(v, 0.f);
     if (P.acc) v += P.C[(size_t)m * P.ldc + n];
     P.C[(size_t)m * P.ldc + n] = v;
 }
 
 /* desc: HOST array, 16 int64 per problem:
- *   [0] A  [1] B  [2] part (f32[ceil(K/64)][32][N] scratch)  [3] C (0 = leave the slabs to the consumer)
- *   [4] bias (0 = none)  [5] lda  [6] ldb  [7] ldc  [8] M (<=32)  [9] N  [10] K  [11] trans_b  [12] accumulate */
-extern "C" int eventad_gemm_m32_group(int n_prob, const int64_t* desc, void* stream) {
-    if (n_prob < 1 || n_prob > M32_MAXP || !desc) return EVAD_ERR_ARG;
-    M32Group g;
+ *   [0] A  [1] B  [2] part (f32[ceil(K/64)][M][N] scratch; unused when K <= 64)  [3] C  [4] bias (0 = none)
+ *   [5] lda  [6] ldb  [7] ldc  [8] M  [9] N  [10] K  [11] trans_a  [12] trans_b  [13] accumulate  [14] relu */
+extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream) {
+    if (n_prob < 1 || n_prob > TG_MAXP || !desc) return EVAD_ERR_ARG;
+    TGroup g;
     g.n = n_prob;
-    int blocks = 0, max_mn = 0, any_c = 0;
+    int blocks = 0, max_mn = 0, any_split = 0;
     for (int i = 0; i < n_prob; ++i) {
         const int64_t* d = desc + 16 * i;
-        M32Prob& P = g.p[i];
+        TProb& P = g.p[i];
         P.A = (const float*)d[0]; P.B = (const float*)d[1]; P.part = (float*)d[2]; P.C = (float*)d[3]; P.bias = (const float*)d[4];
         P.lda = (int)d[5]; P.ldb = (int)d[6]; P.ldc = (int)d[7]; P.M = (int)d[8]; P.N = (int)d[9]; P.K = (int)d[10];
-        P.tb = (int)d[11]; P.acc = (int)d[12];
-        if (!P.A || !P.B || !P.part || P.M < 1 || P.M > 32 || P.N < 1 || P.K < 1 || (P.lda & 3) || (P.ldb & 3) ||
-            !al16(P.A) || !al16(P.B))
+        P.ta = (int)d[11]; P.tb = (int)d[12]; P.acc = (int)d[13]; P.relu = (int)d[14];
+        if (!P.A || !P.B || !P.C || P.M < 1 || P.N < 1 || P.K < 1 || (P.lda & 3) || (P.ldb & 3) || !al16(P.A) || !al16(P.B) ||
+            P.ldc < P.N || P.lda < (P.ta ? P.M : P.K) || P.ldb < (P.tb ? P.K : P.N))
             return EVAD_ERR_ARG;
-        P.tiles_n = (P.N + 31) / 32; P.ksplit = (P.K + 63) / 64; P.block0 = blocks;
-        blocks += P.tiles_n * P.ksplit;
-        if (P.M * P.N > max_mn) max_mn = P.M * P.N;
-        if (P.C) any_c = 1;
+        P.tiles_m = (P.M + 31) / 32; P.tiles_n = (P.N + 31) / 32; P.ksplit = (P.K + 63) / 64; P.block0 = blocks;
+        if (P.ksplit > 1 && !P.part) return EVAD_ERR_ARG;
+        blocks += P.tiles_m * P.tiles_n * P.ksplit;
+        if (P.ksplit > 1) { any_split = 1; if (P.M * P.N > max_mn) max_mn = P.M * P.N; }
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_m32_splitk, dim3(blocks), dim3(64), 0, st, g);
-    if (any_c) hipLaunchKernelGGL(k_m32_reduce, dim3(evad_blocks(max_mn, 256), n_prob), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(k_tile_splitk, dim3(blocks), dim3(64), 0, st, g);
+    if (any_split) hipLaunchKernelGGL(k_tile_reduce, dim3(evad_blocks(max_mn, 256), n_prob), dim3(256), 0, st, g);
     return evad_last_error();
 }

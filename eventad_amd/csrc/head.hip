@@ -87,6 +87,75 @@ extern "C" int eventad_gru_cell_fwd(const float* gi, const float* gh, const floa
     return evad_last_error();
 }
 
+struct CellProb { const float* a; const float* b; const float* c; const float* d; const float* e; const float* f;
+                  const float* g2; float* o0; float* o1; float* o2; int H; };
+struct CellGroup { CellProb p[3]; int n; };
+
+__global__ void k_gru_cell_fwd_g(CellGroup g) {
+    const CellProb& P = g.p[blockIdx.y];
+    int t = blockIdx.x * blockDim.x + threadIdx.x, H = P.H;
+    if (t >= NT * H) return;
+    int row = t / H, j = t % H;
+    const float* a = P.a + (size_t)row * 3 * H; const float* c = P.b + (size_t)row * 3 * H;        // gi, gh
+    float r = sigmoidf_(a[j] + c[j]);
+    float z = sigmoidf_(a[H + j] + c[H + j]);
+    float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    float h = P.c[t];                                                                               // hprev
+    float hn = (1.f - z) * n + z * h;
+    float* gt = P.o0 + (size_t)row * 3 * H;                                                         // gates
+    gt[j] = r; gt[H + j] = z; gt[2 * H + j] = n;
+    P.o1[t] = hn;                                                                                   // hnew
+    if (P.o2) P.o2[t] = P.d ? hn * P.d[t] : hn;                                                     // xdrop, mask
+}
+
+__global__ void k_gru_cell_bwd_g(CellGroup g) {
+    const CellProb& P = g.p[blockIdx.y];
+    int t = blockIdx.x * blockDim.x + threadIdx.x, H = P.H;
+    if (t >= NT * H) return;
+    int row = t / H, j = t % H;
+    float dh = P.a[t];                                                                              // dhn
+    if (P.b) dh += P.c ? P.b[t] * P.c[t] : P.b[t];                                                  // dx_extra, mask
+    const float* gt = P.d + (size_t)row * 3 * H;                                                    // gates
+    float r = gt[j], z = gt[H + j], n = gt[2 * H + j];
+    float ghn = P.e[(size_t)row * 3 * H + 2 * H + j];                                               // gh
+    float h = P.f[t];                                                                               // hprev
+    float dn = dh * (1.f - z), dz = dh * (h - n);
+    float dan = dn * (1.f - n * n), daz = dz * z * (1.f - z), dar = dan * ghn * r * (1.f - r);
+    float* a = P.o0 + (size_t)row * 3 * H; float* c = P.o1 + (size_t)row * 3 * H;                  // dgi, dgh
+    a[j] = dar; a[H + j] = daz; a[2 * H + j] = dan;
+    c[j] = dar; c[H + j] = daz; c[2 * H + j] = dan * r;
+    P.o2[t] = P.g2[t] + dh * z;                                                                     // dsprev = dspass + dh*z
+}
+
+extern "C" int eventad_gru_cell_fwd_group(int n, const int64_t* desc, void* stream) {
+    if (n < 1 || n > 3 || !desc) return EVAD_ERR_ARG;
+    CellGroup g; g.n = n; int hmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* q = desc + 12 * i; CellProb& P = g.p[i];
+        P.a = (const float*)q[0]; P.b = (const float*)q[1]; P.c = (const float*)q[2]; P.o0 = (float*)q[3]; P.o1 = (float*)q[4];
+        P.d = (const float*)q[5]; P.o2 = (float*)q[6]; P.H = (int)q[7];
+        if (!P.a || !P.b || !P.c || !P.o0 || !P.o1 || P.H <= 0) return EVAD_ERR_ARG;
+        if (P.H > hmax) hmax = P.H;
+    }
+    hipLaunchKernelGGL(k_gru_cell_fwd_g, dim3(evad_blocks(NT * hmax, 256), n), dim3(256), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}
+
+extern "C" int eventad_gru_cell_bwd_group(int n, const int64_t* desc, void* stream) {
+    if (n < 1 || n > 3 || !desc) return EVAD_ERR_ARG;
+    CellGroup g; g.n = n; int hmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* q = desc + 12 * i; CellProb& P = g.p[i];
+        P.a = (const float*)q[0]; P.b = (const float*)q[1]; P.c = (const float*)q[2]; P.d = (const float*)q[3];
+        P.e = (const float*)q[4]; P.f = (const float*)q[5]; P.g2 = (const float*)q[6]; P.o0 = (float*)q[7];
+        P.o1 = (float*)q[8]; P.o2 = (float*)q[9]; P.H = (int)q[10];
+        if (!P.a || !P.d || !P.e || !P.f || !P.g2 || !P.o0 || !P.o1 || !P.o2 || P.H <= 0) return EVAD_ERR_ARG;
+        if (P.H > hmax) hmax = P.H;
+    }
+    hipLaunchKernelGGL(k_gru_cell_bwd_g, dim3(evad_blocks(NT * hmax, 256), n), dim3(256), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}
+
 // dh = dHn (+ dx_extra*mask);  dn = dh*(1-z), dz = dh*(h-n), dh_prev = dSpass + dh*z;
 // dgi = (da_r, da_z, da_n), dgh = (da_r, da_z, da_n*r)  with da_n = dn*(1-n^2), da_z = dz*z(1-z),
 // da_r = da_n*gh_n*r(1-r).
@@ -133,22 +202,30 @@ struct AttGroup { AttProb p[3]; const int* valid; int n; };
 __device__ __forceinline__ float wave_sum(float v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64)); return v; }
 
+// Thread t owns hidden column(s) j = t, t+256, ... and walks the 32 track rows with all loads independent
+// (one memory round trip instead of 8 serial row passes); the per-row dot products are reduced through
+// LDS in a fixed order.
 __global__ __launch_bounds__(256) void k_att_fwd(AttGroup g) {
-    __shared__ float s_s[NT], s_a[NT];
+    __shared__ float s_part[4][NT], s_a[NT];
     __shared__ int s_v[NT];
     const AttProb& P = g.p[blockIdx.x];
-    const int H = P.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < NT) s_v[threadIdx.x] = g.valid[threadIdx.x];
-    for (int k = wave; k < NT; k += 4) {
-        float acc = 0.f;
-        for (int j = lane; j < H; j += 64) acc += tanhf(P.Hn[(size_t)k * H + j]) * P.w[j];
-        acc = wave_sum(acc);
-        if (lane == 0) s_s[k] = acc;
+    const int H = P.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < NT) s_v[tid] = g.valid[tid];
+    float hn[NT];
+    const bool act = tid < H;                               // H = 256 or 32
+    const float wj = act ? P.w[tid] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) hn[k] = act ? P.Hn[(size_t)k * H + tid] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        float v = wave_sum(act ? tanhf(hn[k]) * wj : 0.f);
+        if (lane == 0) s_part[wave][k] = v;
     }
     __syncthreads();
     if (wave == 0) {                                         // masked softmax over the 32 track slots
         bool v = lane < NT && s_v[lane];
-        float sv = v ? s_s[lane] : -3.4e38f;
+        float sv = lane < NT ? ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane] : 0.f;
+        sv = v ? sv : -3.4e38f;
         float m = wave_max(sv);
         float e = v ? expf(sv - m) : 0.f;
         float sum = wave_sum(e);
@@ -156,49 +233,55 @@ __global__ __launch_bounds__(256) void k_att_fwd(AttGroup g) {
         if (lane < NT) { s_a[lane] = a; P.alpha[lane] = a; }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < NT * H; t += 256) {
-        int k = t / H;
-        P.Snext[t] = s_v[k] ? P.Hn[t] * s_a[k] : P.Sprev[t];
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) P.Snext[(size_t)k * H + tid] = s_v[k] ? hn[k] * s_a[k] : P.Sprev[(size_t)k * H + tid];
     }
 }
 
 // backward: dHn (total, incl. dHn_out from the fusion / next-layer branch), dSpass (rows whose state was
-// kept), dw += this clip's contribution (deterministic: fixed summation order inside one workgroup).
+// kept), dw += this clip's contribution (fixed summation order inside one workgroup).
 __global__ __launch_bounds__(256) void k_att_bwd(AttGroup g) {
-    __shared__ float s_da[NT], s_ds[NT], s_al[NT];
+    __shared__ float s_part[4][NT], s_ds[NT], s_al[NT];
     __shared__ int s_v[NT];
     const AttProb& P = g.p[blockIdx.x];
-    const int H = P.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < NT) { s_v[threadIdx.x] = g.valid[threadIdx.x]; s_al[threadIdx.x] = P.alpha[threadIdx.x]; }
+    const int H = P.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < NT) { s_v[tid] = g.valid[tid]; s_al[tid] = P.alpha[tid]; }
+    const bool act = tid < H;
+    float hn[NT], gs[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) { hn[k] = act ? P.Hn[(size_t)k * H + tid] : 0.f; gs[k] = act ? P.dSnext[(size_t)k * H + tid] : 0.f; }
     __syncthreads();
-    for (int k = wave; k < NT; k += 4) {
-        float acc = 0.f;
-        if (s_v[k]) for (int j = lane; j < H; j += 64) acc += P.dSnext[(size_t)k * H + j] * P.Hn[(size_t)k * H + j];
-        acc = wave_sum(acc);
-        if (lane == 0) s_da[k] = acc;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        float v = wave_sum(s_v[k] ? gs[k] * hn[k] : 0.f);
+        if (lane == 0) s_part[wave][k] = v;
     }
     __syncthreads();
     if (wave == 0) {
         bool v = lane < NT && s_v[lane];
-        float a = v ? s_al[lane] : 0.f, da = v ? s_da[lane] : 0.f;
+        float da = lane < NT ? ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane] : 0.f;
+        float a = v ? s_al[lane] : 0.f;
+        da = v ? da : 0.f;
         float dot = wave_sum(a * da);
         if (lane < NT) s_ds[lane] = v ? a * (da - dot) : 0.f;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < NT * H; t += 256) {
-        int k = t / H, j = t % H;
-        float gr = P.dSnext[t];
-        if (s_v[k]) {
-            float th = tanhf(P.Hn[t]);
-            float d = gr * s_al[k] + s_ds[k] * P.w[j] * (1.f - th * th);
-            if (P.dHn_out) d += P.dHn_out[t];
-            P.dHn[t] = d; P.dSpass[t] = 0.f;
-        } else { P.dHn[t] = 0.f; P.dSpass[t] = gr; }
-    }
-    for (int j = threadIdx.x; j < H; j += 256) {
-        float acc = 0.f;
-        for (int k = 0; k < NT; ++k) if (s_v[k]) acc += s_ds[k] * tanhf(P.Hn[(size_t)k * H + j]);
-        P.dw[j] += acc;                 // every problem of a launch owns its own dw accumulator
+    if (act) {
+        const float wj = P.w[tid];
+        float dwj = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            size_t o = (size_t)k * H + tid;
+            if (s_v[k]) {
+                float th = tanhf(hn[k]);
+                float d = gs[k] * s_al[k] + s_ds[k] * wj * (1.f - th * th);
+                if (P.dHn_out) d += P.dHn_out[o];
+                P.dHn[o] = d; P.dSpass[o] = 0.f;
+                dwj += s_ds[k] * th;
+            } else { P.dHn[o] = 0.f; P.dSpass[o] = gs[k]; }
+        }
+        P.dw[tid] += dwj;                                   // every problem of a launch owns its own dw accumulator
     }
 }
 
@@ -325,6 +408,32 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
     if (w == 0 && n < N) out[n] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+struct ColGroup { const float* A[8]; float* out[8]; int lda[8], N[8]; int R, n; };
+__global__ __launch_bounds__(256) void k_colsum_g(ColGroup g) {
+    __shared__ float red[4][64];
+    int pi = blockIdx.y, N = g.N[pi];
+    int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    if (blockIdx.x * 64 >= N) return;
+    float s = 0.f;
+    if (n < N) for (int r = w; r < g.R; r += 4) s += g.A[pi][(size_t)r * g.lda[pi] + n];
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && n < N) g.out[pi][n] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+/* desc: HOST array, 4 int64 per problem: [0] A [1] out [2] lda [3] N; all problems have R rows. */
+extern "C" int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream) {
+    if (n < 1 || n > 8 || !desc || R <= 0) return EVAD_ERR_ARG;
+    ColGroup g; g.n = n; g.R = R; int nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        g.A[i] = (const float*)desc[4 * i]; g.out[i] = (float*)desc[4 * i + 1]; g.lda[i] = (int)desc[4 * i + 2]; g.N[i] = (int)desc[4 * i + 3];
+        if (!g.A[i] || !g.out[i] || g.N[i] <= 0 || g.lda[i] < g.N[i]) return EVAD_ERR_ARG;
+        if (g.N[i] > nmax) nmax = g.N[i];
+    }
+    hipLaunchKernelGGL(k_colsum_g, dim3(evad_blocks(nmax, 64), n), dim3(256), 0, (hipStream_t)stream, g);
+    return evad_last_error();
 }
 
 extern "C" int eventad_colsum(const float* A, int lda, int R, int N, float* out, void* stream) {

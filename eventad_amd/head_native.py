@@ -94,28 +94,36 @@ class NativeHead:
         for k, n in (("dS0a", 256), ("dS0b", 256), ("dS1a", 256), ("dS1b", 256), ("dSCa", 32), ("dSCb", 32),
                      ("dHn0", 256), ("dHn1", 256), ("dHnC", 32), ("dSp0", 256), ("dSp1", 256), ("dSpC", 32), ("dX1", 256)):
             w[k] = f(NT, n)
-        w["part"] = [f(12 * 32 * 768) for _ in range(4)]                        # split-K slabs, one per grouped problem
+        w["part"] = [f(4 * 768 * 256) for _ in range(8)]                        # split-K slabs, one per grouped problem (3 MB)
         w["dwatt0"], w["dwatt1"] = f(256), f(256)                               # per-layer accumulators of d soft_attention.weight
         self._B = B
 
-    def _m32(self, *probs):
-        """Grouped skinny GEMMs: each prob = (A, lda, B, ldb, C, ldc, M, N, K, trans_b, bias, accumulate)."""
+    # ------------------------------------------------------------ launch helpers
+    def _gg(self, *probs):
+        """One grouped-GEMM launch.  prob = (ta, tb, A, lda, B, ldb, C, ldc, M, N, K[, bias[, relu[, acc]]])."""
         d = (ctypes.c_int64 * (16 * len(probs)))()
-        for i, (A, lda, Bm, ldb, C, ldc, M, N, K, tb, bias, acc) in enumerate(probs):
-            d[16 * i:16 * i + 13] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr(), C.data_ptr(),
-                                     bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, tb, acc]
-        call("eventad_gemm_m32_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
+        for i, pr in enumerate(probs):
+            ta, tb, A, lda, Bm, ldb, C, ldc, M, N, K = pr[:11]
+            bias = pr[11] if len(pr) > 11 else None
+            relu = pr[12] if len(pr) > 12 else 0
+            acc = pr[13] if len(pr) > 13 else 0
+            assert ((K + 63) // 64) * M * N <= self.w["part"][i].numel()
+            d[16 * i:16 * i + 15] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr(), C.data_ptr(),
+                                     bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu]
+        call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _desc(fn, width, rows, *extra):
+        d = (ctypes.c_int64 * (width * len(rows)))()
+        for i, row in enumerate(rows):
+            for j, v in enumerate(row):
+                d[width * i + j] = v if isinstance(v, int) else (v.data_ptr() if v is not None else 0)
+        call(fn, len(rows), ctypes.cast(d, ctypes.c_void_p), *extra, torch.cuda.current_stream().cuda_stream)
 
     def _att(self, fn, valid, *probs):
         """Grouped attentions: prob = dict(Hn, Sprev, w, alpha, Snext, dSnext, dHn_out, dHn, dSpass, dw, H)."""
-        keys = ("Hn", "Sprev", "w", "alpha", "Snext", "dSnext", "dHn_out", "dHn", "dSpass", "dw")
-        d = (ctypes.c_int64 * (12 * len(probs)))()
-        for i, pr in enumerate(probs):
-            for j, k in enumerate(keys):
-                t = pr.get(k)
-                d[12 * i + j] = t.data_ptr() if t is not None else 0
-            d[12 * i + 10] = pr["H"]
-        call(fn, len(probs), ctypes.cast(d, ctypes.c_void_p), _rp(valid), torch.cuda.current_stream().cuda_stream)
+        keys = ("Hn", "Sprev", "w", "alpha", "Snext", "dSnext", "dHn_out", "dHn", "dSpass", "dw", "H")
+        self._desc(fn, 12, [[pr.get(k) for k in keys] for pr in probs], _rp(valid))
 
     @staticmethod
     def _gemm(ta, tb, A, lda, Bm, ldb, C, ldc, M, N, K, bias=None, relu=0, acc=0):
@@ -127,7 +135,7 @@ class NativeHead:
         """feats f32[B,2,31,64] (ROI features), bbox f32[M,6], bbox_batch i64[M], labels f32[M] or None.
         Returns (loss 0-d, logits [B,32,2], valid bool[B,32], targets i64[B,32]); keeps what backward needs."""
         self._alloc(B)
-        w, P, g = self.w, self.P, self._gemm
+        w, P = self.w, self.P
         st = torch.cuda.current_stream().cuda_stream
         R = B * NT
         M = int(bbox.shape[0]) if bbox is not None else 0
@@ -141,32 +149,32 @@ class NativeHead:
             self.D1 = torch.bernoulli(torch.full((R, 256), 0.7, device=self.dev)) / 0.7
             self.D2 = torch.bernoulli(torch.full((R, 256), 0.7, device=self.dev)) / 0.7
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
-        g(0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, bias=P[ev + "bias_ih_l0"])
-        g(0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, bias=P[co + "bias_ih_l0"])
-        w["S0"][:NT].zero_(); w["S1"][:NT].zero_(); w["SC"][:NT].zero_()
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
+        # input projections of every clip at once
+        self._gg((0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, P[ev + "bias_ih_l0"]),
+                 (0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, P[co + "bias_ih_l0"]))
+        w["S0"][:NT].zero_(); w["S1"][:NT].zero_(); w["SC"][:NT].zero_()
         for b in range(B):                                     # the clip-to-clip hidden-state chain (EventAD.py:211-323)
             r0, r1 = b * NT, (b + 1) * NT
             vb = w["valid"][r0:r1]
-            self._m32((w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, 1, P[ev + "bias_hh_l0"], 0),
-                      (w["S1"][r0:r1], 256, P[ev + "weight_hh_l1"], 256, w["GH1"][r0:r1], 768, NT, 768, 256, 1, P[ev + "bias_hh_l1"], 0),
-                      (w["SC"][r0:r1], 32, P[co + "weight_hh_l0"], 32, w["GHC"][r0:r1], 96, NT, 96, 32, 1, P[co + "bias_hh_l0"], 0))
+            self._gg((0, 1, w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, P[ev + "bias_hh_l0"]),
+                     (0, 1, w["S1"][r0:r1], 256, P[ev + "weight_hh_l1"], 256, w["GH1"][r0:r1], 768, NT, 768, 256, P[ev + "bias_hh_l1"]),
+                     (0, 1, w["SC"][r0:r1], 32, P[co + "weight_hh_l0"], 32, w["GHC"][r0:r1], 96, NT, 96, 32, P[co + "bias_hh_l0"]))
             d1 = self.D1[r0:r1] if train else None
-            call("eventad_gru_cell_fwd", _rp(w["GI0"][r0:r1]), _rp(w["GH0"][r0:r1]), _rp(w["S0"][r0:r1]), NT, 256,
-                 _rp(w["G0"][r0:r1]), _rp(w["H0n"][r0:r1]), _rp(d1), _rp(w["X1"][r0:r1]), st)
-            call("eventad_gru_cell_fwd", _rp(w["GIC"][r0:r1]), _rp(w["GHC"][r0:r1]), _rp(w["SC"][r0:r1]), NT, 32,
-                 _rp(w["GC"][r0:r1]), _rp(w["HCn"][r0:r1]), None, None, st)
-            self._m32((w["X1"][r0:r1], 256, P[ev + "weight_ih_l1"], 256, w["GI1"][r0:r1], 768, NT, 768, 256, 1, P[ev + "bias_ih_l1"], 0))
-            call("eventad_gru_cell_fwd", _rp(w["GI1"][r0:r1]), _rp(w["GH1"][r0:r1]), _rp(w["S1"][r0:r1]), NT, 256,
-                 _rp(w["G1"][r0:r1]), _rp(w["H1n"][r0:r1]), None, None, st)
+            self._desc("eventad_gru_cell_fwd_group", 12,
+                       [[w["GI0"][r0:r1], w["GH0"][r0:r1], w["S0"][r0:r1], w["G0"][r0:r1], w["H0n"][r0:r1], d1, w["X1"][r0:r1], 256],
+                        [w["GIC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["GC"][r0:r1], w["HCn"][r0:r1], None, None, 32]])
+            self._gg((0, 1, w["X1"][r0:r1], 256, P[ev + "weight_ih_l1"], 256, w["GI1"][r0:r1], 768, NT, 768, 256, P[ev + "bias_ih_l1"]))
+            self._desc("eventad_gru_cell_fwd_group", 12,
+                       [[w["GI1"][r0:r1], w["GH1"][r0:r1], w["S1"][r0:r1], w["G1"][r0:r1], w["H1n"][r0:r1], None, None, 256]])
             self._att("eventad_att_fwd_group", vb,
                       dict(Hn=w["H0n"][r0:r1], Sprev=w["S0"][r0:r1], w=watt, alpha=w["AL0"][r0:r1], Snext=w["S0"][r1:r1 + NT], H=256),
                       dict(Hn=w["H1n"][r0:r1], Sprev=w["S1"][r0:r1], w=watt, alpha=w["AL1"][r0:r1], Snext=w["S1"][r1:r1 + NT], H=256),
                       dict(Hn=w["HCn"][r0:r1], Sprev=w["SC"][r0:r1], w=wattc, alpha=w["ALC"][r0:r1], Snext=w["SC"][r1:r1 + NT], H=32))
         # fusion MLP on all rows at once (Fuse_GRUNet.forward, EventAD.py:30-59)
-        g(0, 1, w["H1n"], 256, P[fu + "event_proj.weight"], 256, w["ZCAT"], 512, R, 256, 256, bias=P[fu + "event_proj.bias"])
-        g(0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, bias=P[fu + "coord_proj.bias"])
-        g(0, 1, w["ZCAT"], 512, P[fu + "fusion.0.weight"], 512, w["F1r"], 256, R, 256, 512, bias=P[fu + "fusion.0.bias"], relu=1)
+        self._gg((0, 1, w["H1n"], 256, P[fu + "event_proj.weight"], 256, w["ZCAT"], 512, R, 256, 256, P[fu + "event_proj.bias"]),
+                 (0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, P[fu + "coord_proj.bias"]))
+        self._gg((0, 1, w["ZCAT"], 512, P[fu + "fusion.0.weight"], 512, w["F1r"], 256, R, 256, 512, P[fu + "fusion.0.bias"], 1))
         call("eventad_fuse_out", ptr(w["F1r"]), _rp(self.D2), _rp(P[fu + "fusion.3.weight"]), _rp(P[fu + "fusion.3.bias"]),
              ptr(w["target"]), ptr(w["valid"]), R, ptr(w["logits"]), ptr(w["dlog"]), ptr(w["loss_rows"]), ptr(w["loss"]), st)
         self._fw = (B, train)
@@ -176,23 +184,22 @@ class NativeHead:
     def backward(self):
         """Fills `self.grads` (d loss / d every used parameter) for the last forward."""
         B, train = self._fw
-        w, P, G, g = self.w, self.P, self.G, self._gemm
+        w, P, G = self.w, self.P, self.G
         st = torch.cuda.current_stream().cuda_stream
         R = B * NT
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
         self.grads.zero_()
         call("eventad_out_bwd", ptr(w["dlog"]), _rp(P[fu + "fusion.3.weight"]), ptr(w["F1r"]), _rp(self.D2), R, ptr(w["dPre"]),
              _rp(G[fu + "fusion.3.weight"]), _rp(G[fu + "fusion.3.bias"]), st)
-        g(1, 0, w["dPre"], 256, w["ZCAT"], 512, G[fu + "fusion.0.weight"], 512, 256, 512, R)
-        call("eventad_colsum", ptr(w["dPre"]), 256, R, 256, _rp(G[fu + "fusion.0.bias"]), st)
-        g(0, 0, w["dPre"], 256, P[fu + "fusion.0.weight"], 512, w["dZCAT"], 512, R, 512, 256)
         dE, dC = w["dZCAT"], w["dZCAT"][:, 256:]
-        g(1, 0, dE, 512, w["H1n"], 256, G[fu + "event_proj.weight"], 256, 256, 256, R)
-        call("eventad_colsum", _rp(dE), 512, R, 256, _rp(G[fu + "event_proj.bias"]), st)
-        g(0, 0, dE, 512, P[fu + "event_proj.weight"], 256, w["dH1o"], 256, R, 256, 256)
-        g(1, 0, dC, 512, w["HCn"], 32, G[fu + "coord_proj.weight"], 32, 256, 32, R)
-        call("eventad_colsum", _rp(dC), 512, R, 256, _rp(G[fu + "coord_proj.bias"]), st)
-        g(0, 0, dC, 512, P[fu + "coord_proj.weight"], 32, w["dHCo"], 32, R, 32, 256)
+        self._gg((1, 0, w["dPre"], 256, w["ZCAT"], 512, G[fu + "fusion.0.weight"], 512, 256, 512, R),
+                 (0, 0, w["dPre"], 256, P[fu + "fusion.0.weight"], 512, w["dZCAT"], 512, R, 512, 256))
+        self._gg((1, 0, dE, 512, w["H1n"], 256, G[fu + "event_proj.weight"], 256, 256, 256, R),
+                 (0, 0, dE, 512, P[fu + "event_proj.weight"], 256, w["dH1o"], 256, R, 256, 256),
+                 (1, 0, dC, 512, w["HCn"], 32, G[fu + "coord_proj.weight"], 32, 256, 32, R),
+                 (0, 0, dC, 512, P[fu + "coord_proj.weight"], 32, w["dHCo"], 32, R, 32, 256))
+        self._desc("eventad_colsum_group", 4, [[w["dPre"], G[fu + "fusion.0.bias"], 256, 256], [dE, G[fu + "event_proj.bias"], 512, 256],
+                                               [dC, G[fu + "coord_proj.bias"], 512, 256]], R)
         d0, d1, dc = w["dS0a"], w["dS1a"], w["dSCa"]
         n0, n1, nc = w["dS0b"], w["dS1b"], w["dSCb"]
         d0.zero_(); d1.zero_(); dc.zero_()
@@ -209,30 +216,34 @@ class NativeHead:
                            dSpass=w["dSpC"], dw=gattc, H=32),
                       dict(Hn=w["H0n"][r0:r1], w=watt, alpha=w["AL0"][r0:r1], dSnext=d0, dHn_out=None, dHn=w["dHn0"],
                            dSpass=w["dSp0"], dw=w["dwatt0"], H=256))
-            call("eventad_gru_cell_bwd", _rp(w["dHn1"]), None, None, _rp(w["G1"][r0:r1]), _rp(w["GH1"][r0:r1]), _rp(w["S1"][r0:r1]),
-                 _rp(w["dSp1"]), NT, 256, _rp(w["dGI1"][r0:r1]), _rp(w["dGH1"][r0:r1]), _rp(n1), st)
-            call("eventad_gru_cell_bwd", _rp(w["dHnC"]), None, None, _rp(w["GC"][r0:r1]), _rp(w["GHC"][r0:r1]), _rp(w["SC"][r0:r1]),
-                 _rp(w["dSpC"]), NT, 32, _rp(w["dGIC"][r0:r1]), _rp(w["dGHC"][r0:r1]), _rp(nc), st)
-            self._m32((w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, 0, None, 1),
-                      (w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, 0, None, 1),
-                      (w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768, 0, None, 0))
+            self._desc("eventad_gru_cell_bwd_group", 12,
+                       [[w["dHn1"], None, None, w["G1"][r0:r1], w["GH1"][r0:r1], w["S1"][r0:r1], w["dSp1"], w["dGI1"][r0:r1],
+                         w["dGH1"][r0:r1], n1, 256],
+                        [w["dHnC"], None, None, w["GC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["dSpC"], w["dGIC"][r0:r1],
+                         w["dGHC"][r0:r1], nc, 32]])
+            self._gg((0, 0, w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, None, 0, 1),
+                     (0, 0, w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, None, 0, 1),
+                     (0, 0, w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768))
             dm = self.D1[r0:r1] if train else None
-            call("eventad_gru_cell_bwd", _rp(w["dHn0"]), _rp(w["dX1"]), _rp(dm), _rp(w["G0"][r0:r1]), _rp(w["GH0"][r0:r1]),
-                 _rp(w["S0"][r0:r1]), _rp(w["dSp0"]), NT, 256, _rp(w["dGI0"][r0:r1]), _rp(w["dGH0"][r0:r1]), _rp(n0), st)
-            self._m32((w["dGH0"][r0:r1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, 0, None, 1))
+            self._desc("eventad_gru_cell_bwd_group", 12,
+                       [[w["dHn0"], w["dX1"], dm, w["G0"][r0:r1], w["GH0"][r0:r1], w["S0"][r0:r1], w["dSp0"], w["dGI0"][r0:r1],
+                         w["dGH0"][r0:r1], n0, 256]])
+            self._gg((0, 0, w["dGH0"][r0:r1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, None, 0, 1))
             d0, n0 = n0, d0
             d1, n1 = n1, d1
             dc, nc = nc, dc
         torch.add(w["dwatt0"], w["dwatt1"], out=G["soft_attention.weight"].view(-1))
-        # weight gradients of the recurrent layers, batched over all clips
-        for pre, dgi, dgh, xin, sst, hin, hh in ((ev, "dGI0", "dGH0", "X", "S0", 64, 256), (ev, "dGI1", "dGH1", "X1", "S1", 256, 256),
-                                                 (co, "dGIC", "dGHC", "CO", "SC", 4, 32)):
-            sfx = "_l1" if dgi == "dGI1" else "_l0"
-            n3 = 3 * hh
-            g(1, 0, w[dgi], n3, w[xin], hin, G[pre + "weight_ih" + sfx], hin, n3, hin, R)
-            g(1, 0, w[dgh], n3, w[sst], hh, G[pre + "weight_hh" + sfx], hh, n3, hh, R)
-            call("eventad_colsum", ptr(w[dgi]), n3, R, n3, _rp(G[pre + "bias_ih" + sfx]), st)
-            call("eventad_colsum", ptr(w[dgh]), n3, R, n3, _rp(G[pre + "bias_hh" + sfx]), st)
+        # weight gradients of the recurrent layers, batched over all clips: ONE launch (+ one reduce)
+        self._gg((1, 0, w["dGI0"], 768, w["X"], 64, G[ev + "weight_ih_l0"], 64, 768, 64, R),
+                 (1, 0, w["dGH0"], 768, w["S0"], 256, G[ev + "weight_hh_l0"], 256, 768, 256, R),
+                 (1, 0, w["dGI1"], 768, w["X1"], 256, G[ev + "weight_ih_l1"], 256, 768, 256, R),
+                 (1, 0, w["dGH1"], 768, w["S1"], 256, G[ev + "weight_hh_l1"], 256, 768, 256, R),
+                 (1, 0, w["dGIC"], 96, w["CO"], 4, G[co + "weight_ih_l0"], 4, 96, 4, R),
+                 (1, 0, w["dGHC"], 96, w["SC"], 32, G[co + "weight_hh_l0"], 32, 96, 32, R))
+        self._desc("eventad_colsum_group", 4,
+                   [[w["dGI0"], G[ev + "bias_ih_l0"], 768, 768], [w["dGH0"], G[ev + "bias_hh_l0"], 768, 768],
+                    [w["dGI1"], G[ev + "bias_ih_l1"], 768, 768], [w["dGH1"], G[ev + "bias_hh_l1"], 768, 768],
+                    [w["dGIC"], G[co + "bias_ih_l0"], 96, 96], [w["dGHC"], G[co + "bias_hh_l0"], 96, 96]], R)
 
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self):

@@ -166,17 +166,24 @@ int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* m
  * valid i32[32] = the clip's track mask (device). */
 int eventad_att_fwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
 int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
-/* Up to 4 independent [M<=32,K]x[K,N] products per launch, split over K into partial slabs and summed in
- * order (deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B [2] part scratch
- * f32[ceil(K/64)][32][N] [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K [11] trans_b
- * [12] accumulate. */
-int eventad_gemm_m32_group(int n_prob, const int64_t* desc, void* stream);
+/* Up to 8 independent small GEMMs per launch (one wave per 32x32 tile and 64-deep K chunk; K chunks summed
+ * in order = deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B [2] part scratch
+ * f32[ceil(K/64)][M][N] (unused when K<=64) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K
+ * [11] trans_a [12] trans_b [13] accumulate [14] relu. */
+int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream);
+/* Up to 3 GRU cells per launch.  desc = HOST array, 12 int64 per cell: fwd [0] gi [1] gh [2] hprev [3] gates
+ * [4] hnew [5] mask(0) [6] xdrop(0) [7] H; bwd [0] dhn [1] dx_extra(0) [2] mask(0) [3] gates [4] gh [5] hprev
+ * [6] dspass [7] dgi [8] dgh [9] dsprev [10] H.  rows = 32 (one clip). */
+int eventad_gru_cell_fwd_group(int n, const int64_t* desc, void* stream);
+int eventad_gru_cell_bwd_group(int n, const int64_t* desc, void* stream);
 /* fusion[3] Linear(256,2) + summed cross-entropy (EventAD.py:27,280-281) and its backward. */
 int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
                      const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss, void* stream);
 int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
                     float* dWo, float* dbo, void* stream);
 int eventad_colsum(const float* A, int lda, int R, int N, float* out, void* stream);
+/* up to 8 column sums per launch; desc = HOST array, 4 int64 per problem: [0] A [1] out [2] lda [3] N */
+int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream);
 /* clip_grad_norm_ + AdamW on flat buffers (utils/train.py:27-53,141-152).  state f32[8]:
  * [0] step, [1] grad norm, [2] clip coefficient, [3] 1-beta1^t, [4] 1-beta2^t, [5] non-finite-norm count. */
 int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr, double beta1,

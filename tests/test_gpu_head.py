@@ -117,3 +117,27 @@ def test_gemm_variants():
         NativeHead._gemm(ta, tb, A, A.shape[1], Bm, Bm.shape[1], C, N, M, N, K, bias=bias, relu=0, acc=1)
         ref = ((A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double() + C0.double()).float()
         assert torch.allclose(C, ref, atol=2e-4, rtol=1e-4), (ta, tb, M, N, K, float((C - ref).abs().max()))
+
+
+def test_grouped_tile_gemm():
+    import ctypes
+    from eventad_amd._lib import call
+    g = torch.Generator().manual_seed(2)
+    shapes = [(0, 1, 32, 768, 256), (0, 0, 32, 256, 768), (1, 0, 768, 64, 256), (0, 1, 256, 96, 4), (1, 0, 96, 4, 256),
+              (0, 0, 256, 32, 256), (0, 1, 20, 70, 36), (1, 1, 100, 52, 40)]
+    probs, refs = [], []
+    for (ta, tb, M, N, K) in shapes:
+        A = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
+        Bm = torch.randn((N, K) if tb else (K, N), generator=g).cuda()
+        C0 = torch.randn(M, N, generator=g).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        C = C0.clone()
+        part = torch.empty(((K + 63) // 64) * M * N, device="cuda")
+        probs.append((A, Bm, part, C, bias, A.shape[1], Bm.shape[1], N, M, N, K, ta, tb, 1, 1))
+        refs.append(torch.relu((A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double()).float() + C0)
+    d = (ctypes.c_int64 * (16 * len(probs)))()
+    for i, pr in enumerate(probs):
+        d[16 * i:16 * i + 15] = [v.data_ptr() if isinstance(v, torch.Tensor) else v for v in pr]
+    call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
+    for pr, ref, shp in zip(probs, refs, shapes):
+        assert torch.allclose(pr[3], ref, atol=2e-4, rtol=1e-4), (shp, float((pr[3] - ref).abs().max()))
