@@ -136,7 +136,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not a.no_graph
+    # hipGraph replay is verified on one GPU; capturing an RCCL all-reduce inside a hipGraph could not be tested on
+    # the 1-GPU development box, so multi-rank runs launch eagerly unless EVENTAD_DDP_GRAPH=1 is set.
+    use_graph = not a.no_graph and (world == 1 or os.environ.get("EVENTAD_DDP_GRAPH") == "1")
     for _ in range(a.warmup):
         ts.step(data)
     if use_graph:

@@ -251,95 +251,102 @@ extern "C" int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int
 }
 
 // =============================================================================================
-// Grouped split-K tile GEMM -- the head's workhorse.
+// Grouped tile GEMM -- the head's workhorse.
 // The head's products are small ([32..768] x [4..768] x [4..768]); as single launches of a 64x64- or
 // 128x128-tiled kernel they fill 4..48 workgroups of a 256-CU chip and walk K serially (measured
-// 15-30 us each).  Here up to 8 independent products go out in ONE launch; every workgroup is one wave
-// that owns a 32x32 output tile and a 64-deep K chunk (=> 100-800 waves per launch, all 16 loads of a
-// wave in flight at once).  K chunks are written as partial slabs part[ks][M][N]; k_tile_reduce then
-// sums the slabs IN ORDER (bitwise reproducible, no float atomics) and applies bias / relu /
-// accumulate.  Products with K <= 64 skip the slab and write C directly.
+// 15-30 us each).  Here up to 8 independent products go out in ONE launch.  A workgroup (4 waves) owns
+// one 32x32 output tile; wave w takes the 64-deep K chunks w, w+4, ... (all 16 loads of a chunk in
+// flight at once, private LDS staging, 32 MFMAs per chunk) and the four partial accumulators are
+// summed through LDS in wave order (bitwise reproducible, no float atomics, no second launch).
 // =============================================================================================
 #define TG_MAXP 8
 struct TProb {
-    const float* A; const float* B; float* part; float* C; const float* bias;
-    int lda, ldb, ldc, M, N, K, ta, tb, acc, relu, tiles_m, tiles_n, ksplit, block0;
+    const float* A; const float* B; float* C; const float* bias; float* part;
+    int lda, ldb, ldc, M, N, K, ta, tb, acc, relu, tiles_m, tiles_n, ksplit, kgroups, block0;
 };
 struct TGroup { TProb p[TG_MAXP]; int n; };
 
-__global__ __launch_bounds__(64) void k_tile_splitk(TGroup g) {
-    __shared__ float As[64][33];
-    __shared__ float Bs[64][33];
+__global__ __launch_bounds__(256) void k_tile_gemm(TGroup g) {
+    __shared__ float As[4][64][33];
+    __shared__ float Bs[4][64][33];
+    __shared__ float Red[3][32][33];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < TG_MAXP; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].block0) pi = i;
     const TProb& P = g.p[pi];
     const int local = blockIdx.x - P.block0;
     const int per_k = P.tiles_m * P.tiles_n;
-    const int ks = local / per_k, rem = local % per_k, mt = rem / P.tiles_n, nt = rem % P.tiles_n;
-    const int m0 = mt * 32, n0 = nt * 32, k0 = ks * 64, lane = threadIdx.x;
-    if (P.ta) {                                             // A stored [K,M]
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int f = lane + 64 * i, kr = f >> 3, mq = (f & 7) * 4, gk = k0 + kr, gm = m0 + mq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < P.K) v = ld4_guard(P.A + (size_t)gk * P.lda + gm, gm, P.M);
-            As[kr][mq] = v.x; As[kr][mq + 1] = v.y; As[kr][mq + 2] = v.z; As[kr][mq + 3] = v.w;
-        }
-    } else {                                                // A stored [M,K]
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int f = lane + 64 * i, row = f >> 4, kq = (f & 15) * 4, gk = k0 + kq, gm = m0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < P.M) v = ld4_guard(P.A + (size_t)gm * P.lda + gk, gk, P.K);
-            As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
-        }
-    }
-    if (P.tb) {                                             // B stored [N,K]
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int f = lane + 64 * i, col = f >> 4, kq = (f & 15) * 4, gn = n0 + col, gk = k0 + kq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gn < P.N) v = ld4_guard(P.B + (size_t)gn * P.ldb + gk, gk, P.K);
-            Bs[kq][col] = v.x; Bs[kq + 1][col] = v.y; Bs[kq + 2][col] = v.z; Bs[kq + 3][col] = v.w;
-        }
-    } else {                                                // B stored [K,N]
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int f = lane + 64 * i, kr = f >> 3, nq = (f & 7) * 4, gk = k0 + kr, gn = n0 + nq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < P.K) v = ld4_guard(P.B + (size_t)gk * P.ldb + gn, gn, P.N);
-            Bs[kr][nq] = v.x; Bs[kr][nq + 1] = v.y; Bs[kr][nq + 2] = v.z; Bs[kr][nq + 3] = v.w;
-        }
-    }
-    __syncthreads();
+    const int kg = local / per_k, rem = local % per_k, mt = rem / P.tiles_n, nt = rem % P.tiles_n;
+    const int m0 = mt * 32, n0 = nt * 32, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*as)[33] = As[wave];
+    float (*bs)[33] = Bs[wave];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {   // one round: this workgroup's 4 K chunks (K > 256 is spread over several workgroups per tile)
+        const int ks = kg * 4 + wave, k0 = ks * 64;
+        const bool live = ks < P.ksplit;
+        if (P.ta) {                                         // A stored [K,M]
 #pragma unroll
-    for (int kk = 0; kk < 64; kk += 2) {
-        int kr = kk + (lane >> 5), c = lane & 31;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kr][c], Bs[kr][c], acc, 0, 0, 0);
-    }
-    const int gn = n0 + (lane & 31);
-    if (gn >= P.N) return;
-    if (P.ksplit == 1) {                                    // whole K in this chunk: finish here
+            for (int i = 0; i < 8; ++i) {
+                int f = lane + 64 * i, kr = f >> 3, mq = (f & 7) * 4, gk = k0 + kr, gm = m0 + mq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && gk < P.K) v = ld4_guard(P.A + (size_t)gk * P.lda + gm, gm, P.M);
+                as[kr][mq] = v.x; as[kr][mq + 1] = v.y; as[kr][mq + 2] = v.z; as[kr][mq + 3] = v.w;
+            }
+        } else {                                            // A stored [M,K]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (gm >= P.M) continue;
-            float v = acc[r];
-            if (P.bias) v += P.bias[gn];
-            if (P.relu) v = fmaxf(v, 0.f);
-            if (P.acc) v += P.C[(size_t)gm * P.ldc + gn];
-            P.C[(size_t)gm * P.ldc + gn] = v;
+            for (int i = 0; i < 8; ++i) {
+                int f = lane + 64 * i, row = f >> 4, kq = (f & 15) * 4, gk = k0 + kq, gm = m0 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && gm < P.M) v = ld4_guard(P.A + (size_t)gm * P.lda + gk, gk, P.K);
+                as[kq][row] = v.x; as[kq + 1][row] = v.y; as[kq + 2][row] = v.z; as[kq + 3][row] = v.w;
+            }
         }
-    } else {
-        float* out = P.part + (size_t)ks * P.M * P.N;
+        if (P.tb) {                                         // B stored [N,K]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (gm < P.M) out[(size_t)gm * P.N + gn] = acc[r];
+            for (int i = 0; i < 8; ++i) {
+                int f = lane + 64 * i, col = f >> 4, kq = (f & 15) * 4, gn = n0 + col, gk = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && gn < P.N) v = ld4_guard(P.B + (size_t)gn * P.ldb + gk, gk, P.K);
+                bs[kq][col] = v.x; bs[kq + 1][col] = v.y; bs[kq + 2][col] = v.z; bs[kq + 3][col] = v.w;
+            }
+        } else {                                            // B stored [K,N]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int f = lane + 64 * i, kr = f >> 3, nq = (f & 7) * 4, gk = k0 + kr, gn = n0 + nq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && gk < P.K) v = ld4_guard(P.B + (size_t)gk * P.ldb + gn, gn, P.N);
+                bs[kr][nq] = v.x; bs[kr][nq + 1] = v.y; bs[kr][nq + 2] = v.z; bs[kr][nq + 3] = v.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 64; kk += 2) {
+            int kr = kk + (lane >> 5), c = lane & 31;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kr][c], bs[kr][c], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Red[wave - 1][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int col = lane & 31, gn = n0 + col;
+        if (gn < P.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gm = m0 + row;
+                if (gm >= P.M) continue;
+                float v = ((acc[r] + Red[0][row][col]) + Red[1][row][col]) + Red[2][row][col];
+                if (P.kgroups > 1) { P.part[((size_t)kg * P.M + gm) * P.N + gn] = v; continue; }
+                if (P.bias) v += P.bias[gn];
+                if (P.relu) v = fmaxf(v, 0.f);
+                if (P.acc) v += P.C[(size_t)gm * P.ldc + gn];
+                P.C[(size_t)gm * P.ldc + gn] = v;
+            }
         }
     }
 }
@@ -348,12 +355,12 @@ __global__ void k_tile_reduce(TGroup g) {
     int pi = blockIdx.y;
     if (pi >= g.n) return;
     const TProb& P = g.p[pi];
-    if (P.ksplit == 1) return;
+    if (P.kgroups == 1) return;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.M * P.N) return;
     int m = t / P.N, n = t % P.N;
     float v = 0.f;
-    for (int ks = 0; ks < P.ksplit; ++ks) v += P.part[((size_t)ks * P.M + m) * P.N + n];
+    for (int q = 0; q < P.kgroups; ++q) v += P.part[((size_t)q * P.M + m) * P.N + n];
     if (P.bias) v += P.bias[n];
     if (P.relu) v = fmaxf(v, 0.f);
     if (P.acc) v += P.C[(size_t)m * P.ldc + n];
@@ -361,13 +368,13 @@ __global__ void k_tile_reduce(TGroup g) {
 }
 
 /* desc: HOST array, 16 int64 per problem:
- *   [0] A  [1] B  [2] part (f32[ceil(K/64)][M][N] scratch; unused when K <= 64)  [3] C  [4] bias (0 = none)
- *   [5] lda  [6] ldb  [7] ldc  [8] M  [9] N  [10] K  [11] trans_a  [12] trans_b  [13] accumulate  [14] relu */
+ *   [0] A  [1] B  [2] part scratch f32[ceil(K/256)][M][N] (needed when K > 256)  [3] C  [4] bias (0 = none)  [5] lda  [6] ldb  [7] ldc  [8] M  [9] N  [10] K
+ *   [11] trans_a  [12] trans_b  [13] accumulate  [14] relu */
 extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream) {
     if (n_prob < 1 || n_prob > TG_MAXP || !desc) return EVAD_ERR_ARG;
     TGroup g;
     g.n = n_prob;
-    int blocks = 0, max_mn = 0, any_split = 0;
+    int blocks = 0, max_mn = 0;
     for (int i = 0; i < n_prob; ++i) {
         const int64_t* d = desc + 16 * i;
         TProb& P = g.p[i];
@@ -378,12 +385,11 @@ extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream)
             P.ldc < P.N || P.lda < (P.ta ? P.M : P.K) || P.ldb < (P.tb ? P.K : P.N))
             return EVAD_ERR_ARG;
         P.tiles_m = (P.M + 31) / 32; P.tiles_n = (P.N + 31) / 32; P.ksplit = (P.K + 63) / 64; P.block0 = blocks;
-        if (P.ksplit > 1 && !P.part) return EVAD_ERR_ARG;
-        blocks += P.tiles_m * P.tiles_n * P.ksplit;
-        if (P.ksplit > 1) { any_split = 1; if (P.M * P.N > max_mn) max_mn = P.M * P.N; }
+        P.kgroups = (P.ksplit + 3) / 4;
+        if (P.kgroups > 1) { if (!P.part) return EVAD_ERR_ARG; if (P.M * P.N > max_mn) max_mn = P.M * P.N; }
+        blocks += P.tiles_m * P.tiles_n * P.kgroups;
     }
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_tile_splitk, dim3(blocks), dim3(64), 0, st, g);
-    if (any_split) hipLaunchKernelGGL(k_tile_reduce, dim3(evad_blocks(max_mn, 256), n_prob), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(k_tile_gemm, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (max_mn) hipLaunchKernelGGL(k_tile_reduce, dim3(evad_blocks(max_mn, 256), n_prob), dim3(256), 0, (hipStream_t)stream, g);
     return evad_last_error();
 }

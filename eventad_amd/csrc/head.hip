@@ -202,87 +202,90 @@ struct AttGroup { AttProb p[3]; const int* valid; int n; };
 __device__ __forceinline__ float wave_sum(float v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64)); return v; }
 
-// Thread t owns hidden column(s) j = t, t+256, ... and walks the 32 track rows with all loads independent
-// (one memory round trip instead of 8 serial row passes); the per-row dot products are reduced through
-// LDS in a fixed order.
-__global__ __launch_bounds__(256) void k_att_fwd(AttGroup g) {
-    __shared__ float s_part[4][NT], s_a[NT];
+// Mapping: thread = (track row k = tid>>3, column chunk c = tid&7); a thread owns H/8 consecutive hidden
+// columns of its row, so every row dot product is H/8 independent loads + FMAs in registers followed by
+// a 3-step reduction over 8 neighbouring lanes (no long shuffle chains, no serial row passes).
+template <int CH>
+__device__ __forceinline__ void att_fwd_body(const AttProb& P, const int* valid) {
+    __shared__ float s_s[NT];
     __shared__ int s_v[NT];
+    const int tid = threadIdx.x, k = tid >> 3, c = tid & 7, H = CH * 8;
+    if (tid < NT) s_v[tid] = valid[tid];
+    const size_t base = (size_t)k * H + c * CH;
+    float hn[CH];
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) hn[i] = P.Hn[base + i];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) part += tanhf(hn[i]) * P.w[c * CH + i];
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+    if (c == 0) s_s[k] = part;
+    __syncthreads();
+    float m = -3.4e38f;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) if (s_v[q]) m = fmaxf(m, s_s[q]);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) if (s_v[q]) sum += expf(s_s[q] - m);
+    const bool v = s_v[k] != 0;
+    const float a = v ? expf(s_s[k] - m) / sum : 0.f;
+    if (c == 0) P.alpha[k] = a;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) P.Snext[base + i] = v ? hn[i] * a : P.Sprev[base + i];
+}
+
+__global__ __launch_bounds__(256) void k_att_fwd(AttGroup g) {
     const AttProb& P = g.p[blockIdx.x];
-    const int H = P.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < NT) s_v[tid] = g.valid[tid];
-    float hn[NT];
-    const bool act = tid < H;                               // H = 256 or 32
-    const float wj = act ? P.w[tid] : 0.f;
-#pragma unroll
-    for (int k = 0; k < NT; ++k) hn[k] = act ? P.Hn[(size_t)k * H + tid] : 0.f;
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        float v = wave_sum(act ? tanhf(hn[k]) * wj : 0.f);
-        if (lane == 0) s_part[wave][k] = v;
-    }
-    __syncthreads();
-    if (wave == 0) {                                         // masked softmax over the 32 track slots
-        bool v = lane < NT && s_v[lane];
-        float sv = lane < NT ? ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane] : 0.f;
-        sv = v ? sv : -3.4e38f;
-        float m = wave_max(sv);
-        float e = v ? expf(sv - m) : 0.f;
-        float sum = wave_sum(e);
-        float a = v ? e / sum : 0.f;
-        if (lane < NT) { s_a[lane] = a; P.alpha[lane] = a; }
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) P.Snext[(size_t)k * H + tid] = s_v[k] ? hn[k] * s_a[k] : P.Sprev[(size_t)k * H + tid];
-    }
+    if (P.H == 256) att_fwd_body<32>(P, g.valid); else att_fwd_body<4>(P, g.valid);
 }
 
 // backward: dHn (total, incl. dHn_out from the fusion / next-layer branch), dSpass (rows whose state was
 // kept), dw += this clip's contribution (fixed summation order inside one workgroup).
-__global__ __launch_bounds__(256) void k_att_bwd(AttGroup g) {
-    __shared__ float s_part[4][NT], s_ds[NT], s_al[NT];
+template <int CH>
+__device__ __forceinline__ void att_bwd_body(const AttProb& P, const int* valid) {
+    constexpr int H = CH * 8;
+    __shared__ float s_da[NT], s_al[NT], s_c[NT][H + 1];
     __shared__ int s_v[NT];
+    const int tid = threadIdx.x, k = tid >> 3, c = tid & 7;
+    if (tid < NT) { s_v[tid] = valid[tid]; s_al[tid] = P.alpha[tid]; }
+    const size_t base = (size_t)k * H + c * CH;
+    float hn[CH], gs[CH];
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { hn[i] = P.Hn[base + i]; gs[i] = P.dSnext[base + i]; }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) part += gs[i] * hn[i];
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+    __syncthreads();
+    if (c == 0) s_da[k] = s_v[k] ? part : 0.f;
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) if (s_v[q]) dot += s_al[q] * s_da[q];
+    const bool v = s_v[k] != 0;
+    const float al = s_al[k], ds = v ? al * (s_da[k] - dot) : 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        float th = tanhf(hn[i]);
+        if (v) {
+            float d = gs[i] * al + ds * P.w[c * CH + i] * (1.f - th * th);
+            if (P.dHn_out) d += P.dHn_out[base + i];
+            P.dHn[base + i] = d; P.dSpass[base + i] = 0.f;
+        } else { P.dHn[base + i] = 0.f; P.dSpass[base + i] = gs[i]; }
+        s_c[k][c * CH + i] = ds * th;
+    }
+    __syncthreads();
+    for (int j = tid; j < H; j += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc += s_c[q][j];
+        P.dw[j] += acc;                                     // every problem of a launch owns its own dw accumulator
+    }
+}
+
+__global__ __launch_bounds__(256) void k_att_bwd(AttGroup g) {
     const AttProb& P = g.p[blockIdx.x];
-    const int H = P.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < NT) { s_v[tid] = g.valid[tid]; s_al[tid] = P.alpha[tid]; }
-    const bool act = tid < H;
-    float hn[NT], gs[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) { hn[k] = act ? P.Hn[(size_t)k * H + tid] : 0.f; gs[k] = act ? P.dSnext[(size_t)k * H + tid] : 0.f; }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        float v = wave_sum(s_v[k] ? gs[k] * hn[k] : 0.f);
-        if (lane == 0) s_part[wave][k] = v;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        bool v = lane < NT && s_v[lane];
-        float da = lane < NT ? ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane] : 0.f;
-        float a = v ? s_al[lane] : 0.f;
-        da = v ? da : 0.f;
-        float dot = wave_sum(a * da);
-        if (lane < NT) s_ds[lane] = v ? a * (da - dot) : 0.f;
-    }
-    __syncthreads();
-    if (act) {
-        const float wj = P.w[tid];
-        float dwj = 0.f;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            size_t o = (size_t)k * H + tid;
-            if (s_v[k]) {
-                float th = tanhf(hn[k]);
-                float d = gs[k] * s_al[k] + s_ds[k] * wj * (1.f - th * th);
-                if (P.dHn_out) d += P.dHn_out[o];
-                P.dHn[o] = d; P.dSpass[o] = 0.f;
-                dwj += s_ds[k] * th;
-            } else { P.dHn[o] = 0.f; P.dSpass[o] = gs[k]; }
-        }
-        P.dw[tid] += dwj;                                   // every problem of a launch owns its own dw accumulator
-    }
+    if (P.H == 256) att_bwd_body<32>(P, g.valid); else att_bwd_body<4>(P, g.valid);
 }
 
 /* desc: HOST array, 12 int64 per problem: [0] Hn [1] Sprev [2] w [3] alpha [4] Snext [5] dSnext [6] dHn_out
@@ -296,7 +299,7 @@ static int att_group(int n, const int64_t* d, const int32_t* valid, AttGroup* g)
         P.Hn = (const float*)q[0]; P.Sprev = (const float*)q[1]; P.w = (const float*)q[2]; P.alpha = (float*)q[3];
         P.Snext = (float*)q[4]; P.dSnext = (const float*)q[5]; P.dHn_out = (const float*)q[6]; P.dHn = (float*)q[7];
         P.dSpass = (float*)q[8]; P.dw = (float*)q[9]; P.H = (int)q[10];
-        if (!P.Hn || !P.w || !P.alpha || P.H <= 0) return EVAD_ERR_ARG;
+        if (!P.Hn || !P.w || !P.alpha || (P.H != 256 && P.H != 32)) return EVAD_ERR_ARG;
     }
     return EVAD_OK;
 }

@@ -94,7 +94,7 @@ class NativeHead:
         for k, n in (("dS0a", 256), ("dS0b", 256), ("dS1a", 256), ("dS1b", 256), ("dSCa", 32), ("dSCb", 32),
                      ("dHn0", 256), ("dHn1", 256), ("dHnC", 32), ("dSp0", 256), ("dSp1", 256), ("dSpC", 32), ("dX1", 256)):
             w[k] = f(NT, n)
-        w["part"] = [f(4 * 768 * 256) for _ in range(8)]                        # split-K slabs, one per grouped problem (3 MB)
+        w["part"] = [f(3 * 256 * 512) for _ in range(8)]                        # K > 256 slabs, one per grouped problem
         w["dwatt0"], w["dwatt1"] = f(256), f(256)                               # per-layer accumulators of d soft_attention.weight
         self._B = B
 
@@ -107,8 +107,7 @@ class NativeHead:
             bias = pr[11] if len(pr) > 11 else None
             relu = pr[12] if len(pr) > 12 else 0
             acc = pr[13] if len(pr) > 13 else 0
-            assert ((K + 63) // 64) * M * N <= self.w["part"][i].numel()
-            d[16 * i:16 * i + 15] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr(), C.data_ptr(),
+            d[16 * i:16 * i + 15] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr() if K > 256 else 0, C.data_ptr(),
                                      bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu]
         call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
 

@@ -166,9 +166,9 @@ int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* m
  * valid i32[32] = the clip's track mask (device). */
 int eventad_att_fwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
 int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
-/* Up to 8 independent small GEMMs per launch (one wave per 32x32 tile and 64-deep K chunk; K chunks summed
- * in order = deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B [2] part scratch
- * f32[ceil(K/64)][M][N] (unused when K<=64) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K
+/* Up to 8 independent small GEMMs per launch (one workgroup per 32x32 tile, its 4 waves split K in 64-deep
+ * chunks and are summed in wave order = deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B
+ * [2] part scratch f32[ceil(K/256)][M][N] (only when K > 256) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K
  * [11] trans_a [12] trans_b [13] accumulate [14] relu. */
 int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream);
 /* Up to 3 GRU cells per launch.  desc = HOST array, 12 int64 per cell: fwd [0] gi [1] gh [2] hprev [3] gates

@@ -132,7 +132,7 @@ def test_grouped_tile_gemm():
         C0 = torch.randn(M, N, generator=g).cuda()
         bias = torch.randn(N, generator=g).cuda()
         C = C0.clone()
-        part = torch.empty(((K + 63) // 64) * M * N, device="cuda")
+        part = torch.empty(((K + 255) // 256) * M * N, device="cuda")
         probs.append((A, Bm, part, C, bias, A.shape[1], Bm.shape[1], N, M, N, K, ta, tb, 1, 1))
         refs.append(torch.relu((A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double()).float() + C0)
     d = (ctypes.c_int64 * (16 * len(probs)))()
