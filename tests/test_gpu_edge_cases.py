@@ -1,0 +1,131 @@
+"""GPU parity on awkward inputs: ragged clips, an empty clip, a hot pixel with more events than the FIFO
+depth (exercises the long-segment ordering kernel), non-monotone timestamps (slow scan path), a
+non-square sensor, a single-event batch, and size-independent properties at the full C2 size."""
+import pytest
+import torch
+
+from eventad_amd import synthetic, weights
+from eventad_amd.batch import EventBatch
+from eventad_amd._lib import call, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(raw, W, H, B):
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    data = dagr_ref.format_data(raw.clone())
+    sd = weights.random_graph_state()
+    (o3, o4), stages = dagr_ref.backbone_forward(sd, data, dagr_ref.make_config(W, H, B), data.image_feats, return_all=True)
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(sd, W, H, dev)
+    res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    torch.cuda.synchronize()
+    flags = nb.check_flags()
+    ws = res["ws"]
+    N = data.pos.shape[0]
+    edges = torch.empty((2, 16 * max(N, 1)), dtype=torch.int64, device="cuda")
+    call("eventad_ell_to_edges", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["sid"]), N, 16, 16 * max(N, 1), ptr(edges),
+         torch.cuda.current_stream().cuda_stream)
+    edges = edges.cpu()[:, : 16 * N]
+    edges = edges[:, edges[1] >= 0]
+    assert torch.equal(edges, stages["edge_index0"])
+    for name, ref in (("out3", o3), ("out4", o4)):
+        o = res[name]
+        n = int(o["n_dev"].item())
+        assert n == ref.x.shape[0], (name, n, ref.x.shape)
+        assert torch.equal(o["batch"][:n].cpu().long(), ref.batch)
+        assert torch.allclose(o["x"][:n].cpu(), ref.x, atol=1e-3, rtol=1e-3), name
+        assert torch.allclose(o["pos"][:n, :2].cpu(), ref.pos[:, :2], atol=1e-7)
+    return flags, res, stages
+
+
+def _clips(W, H, ns, **kw):
+    return [synthetic.make_clip(i, W, H, n, with_image=False, precomputed_feats=True, **kw) for i, n in enumerate(ns)]
+
+
+def test_ragged_clips_and_an_empty_clip():
+    W = H = 64
+    raw = EventBatch.from_clips(_clips(W, H, [1500, 0, 4000, 7]))
+    _run(raw, W, H, 4)
+
+
+def test_hot_pixel_exceeds_fifo_depth():
+    W = H = 64
+    clips = _clips(W, H, [3000, 2500])
+    clips[0]["pos"][500:900] = torch.tensor([10, 20], dtype=torch.int16)        # 400 events in one pixel (> Q = 128)
+    clips[1]["pos"][::3] = torch.tensor([5, 5], dtype=torch.int16)              # ~830 events in one pixel
+    flags, res, stages = _run(EventBatch.from_clips(clips), W, H, 2)
+    assert int(res["ws"]["counters"][1].item()) >= 2                            # long-segment path was taken
+
+
+def test_non_monotone_timestamps_take_the_exact_scan_path():
+    W = H = 64
+    clips = _clips(W, H, [2500, 2500], t_span_us=30000)
+    g = torch.Generator().manual_seed(9)
+    for c in clips:
+        perm = torch.randperm(2500, generator=g)
+        c["t"] = c["t"][perm].contiguous()                                      # ids no longer ordered by time
+    flags, _, _ = _run(EventBatch.from_clips(clips), W, H, 2)
+    assert flags & 1                                                            # EVENTAD_FLAG_T_NOT_MONOTONE raised
+
+
+def test_non_square_sensor():
+    W, H = 96, 64
+    _run(EventBatch.from_clips(_clips(W, H, [3000, 2000])), W, H, 2)
+
+
+def test_single_event_batch():
+    W = H = 64
+    _run(EventBatch.from_clips(_clips(W, H, [1])), W, H, 1)
+
+
+def test_full_size_c2_properties():
+    """At BASELINE.json's C2 size the oracle is too slow for the CI budget: check invariants instead."""
+    from eventad_amd.backbone import NativeBackbone
+    from eventad_amd.dagr.utils.buffers import format_data
+    W, H, n, B, _ = synthetic.CONFIGS["C2"]
+    data = format_data(synthetic.make_config_batch("C2").to("cuda"))
+    nb = NativeBackbone(weights.random_graph_state(), W, H, torch.device("cuda:0"))
+    res = nb.forward(data.pos, data.x, data.batch, B, data.image_feats)
+    torch.cuda.synchronize()
+    assert nb.check_flags() == 0
+    ws = res["ws"]
+    N = B * n
+    sid = ws["sid"].long()
+    assert torch.equal(torch.sort(sid).values, torch.arange(N, device="cuda"))              # a permutation
+    key_s = ws["key_s"].long()
+    assert bool((key_s[1:] >= key_s[:-1]).all())                                            # sorted by pixel
+    same = key_s[1:] == key_s[:-1]
+    assert bool((sid[1:][same] > sid[:-1][same]).all())                                     # stable inside a pixel
+    deg = ws["deg"].long()
+    assert int(deg.min()) >= 1 and int(deg.max()) <= 16
+    src = ws["ell_src"].long()
+    rows = torch.arange(N, device="cuda")
+    assert torch.equal(src[:, 0], rows)                                                     # self edge first
+    k = torch.arange(16, device="cuda").view(1, -1)
+    live = k < deg.view(-1, 1)
+    s_ids, d_ids = sid[src.clamp(min=0)], sid.view(-1, 1).expand(-1, 16)
+    assert bool((s_ids[live] <= d_ids[live]).all())                                         # older -> newer only
+    assert bool((data.batch[s_ids[live]] == data.batch[d_ids[live]]).all())                 # never across clips
+    t_us = (data.pos[:, 2] * 1e6)
+    assert float((t_us[d_ids[live]] - t_us[s_ids[live]]).max()) <= 10000 + 1               # inside the time window
+    px, py = key_s % W, (key_s // W) % H
+    assert int((px[src.clamp(min=0)] - px.view(-1, 1)).abs()[live].max()) <= 3              # inside the radius
+    assert int((py[src.clamp(min=0)] - py.view(-1, 1)).abs()[live].max()) <= 3
+    caps = [2240, 560, 140, 35]
+    for lv, L in enumerate(ws["levels"]):
+        nl = int(L.n_dev.item())
+        cnt = torch.bincount(L.nbatch[:nl].long(), minlength=B)
+        assert int(cnt.max()) <= caps[lv] + 1 and nl > 0                                    # voxel grid bound (+ the t==T quirk)
+        e = int(L.e_dev.item())
+        rp = L.rowptr[: nl + 1].long()
+        assert int(rp[-1]) == e and bool((rp[1:] >= rp[:-1]).all())
+        srcs = L.csr_src[:e].long()
+        dst = torch.repeat_interleave(torch.arange(nl, device="cuda"), rp[1:] - rp[:-1])
+        assert bool((srcs != dst).all()) and int(srcs.max()) < nl                           # no self loops after pooling
+        key = dst * nl + srcs
+        assert bool((key[1:] > key[:-1]).all())                                             # unique, sorted by (dst, src)
+    out4 = res["out4"]
+    n4 = int(out4["n_dev"].item())
+    assert bool(torch.isfinite(out4["x"][:n4]).all()) and float(out4["x"][:n4].min()) >= 0  # ReLU output
