@@ -32,6 +32,9 @@ class NativeBackbone:
         self.device = torch.device(device)
         self.prefix = prefix
         self._ws_key = None
+        # edge-search kernel: -1 = thread per event, ELL row in registers (fastest on C2: 130 us); >0 = LDS-staged strips of
+        # that many pixels (139 us at 64); 0 = batched prefetch (175 us).  All bit-identical (tools/microbench_ell.py).
+        self.strip_width = -1
         self.fused_mark = False        # measured on C2: reference-style search 141 us + separate marking 98 us beats the
                                        # batched search with fused marking (222 us); see tools/microbench_ell.py
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
@@ -153,10 +156,10 @@ class NativeBackbone:
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
              ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), st)
-        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if self.fused_mark else None, ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
+        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if (self.fused_mark or self.strip_width) else None, ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],
-             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, st)
+             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, self.strip_width, st)
         self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
              ptr(w["root1"]), ptr(w["bn1"][0]), ptr(w["bn1"][1]), ptr(ws["y1"]), N, g.steps, K, st)
         self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),

@@ -93,6 +93,10 @@ __global__ void k_fill_edges(const int32_t* __restrict__ batch, const int32_t* _
 
 static int16_t* g_spiral_dev = nullptr;     // small cached device copy of the spiral table
 static int g_spiral_radius = -1;
+// The same table in constant memory: the spiral step index is wave-uniform, so reads through this
+// symbol are scalar loads (s_load through the constant cache) instead of 2 vector loads per step.
+#define SPIRAL_MAX_R 13
+__constant__ int16_t c_spiral[2 * (2 * SPIRAL_MAX_R + 1) * (2 * SPIRAL_MAX_R + 1)];
 
 static int ensure_spiral(int radius, hipStream_t st, int* steps_out) {
     int steps = (2 * radius + 1) * (2 * radius + 1);
@@ -102,6 +106,7 @@ static int ensure_spiral(int radius, hipStream_t st, int* steps_out) {
         if (g_spiral_dev) hipFree(g_spiral_dev);
         if (hipMalloc(&g_spiral_dev, sizeof(int16_t) * 2 * steps) != hipSuccess) { free(host); return -2; }
         hipMemcpyAsync(g_spiral_dev, host, sizeof(int16_t) * 2 * steps, hipMemcpyHostToDevice, st);
+        if (radius <= SPIRAL_MAX_R) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_spiral), host, sizeof(int16_t) * 2 * steps, 0, hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
         free(host);
         g_spiral_radius = radius;
@@ -515,11 +520,145 @@ __global__ __launch_bounds__(256) void k_build_ell_g(const int2* __restrict__ ev
     }
 }
 
+// Thread-per-event walk with (a) the spiral table read through scalar loads and (b) the ELL row kept in
+// registers and written once as 4 x int4 + 2 x uint4.  Measured with PMC counters on C2, the plain walk
+// issues ~620 vector-memory instructions per wave, a third of them 2- and 4-byte scattered stores; on
+// CDNA a load's s_waitcnt also waits for every older store (vmcnt counts both), so stores inside the
+// dependent chain lengthen every later round trip.
+__global__ __launch_bounds__(256) void k_build_ell_reg(const int2* __restrict__ ev2,
+                                                       const int* __restrict__ key_s, const unsigned* __restrict__ start,
+                                                       const unsigned* flags_in, int N, int W, int H, int steps, int Q,
+                                                       int dt_max, int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
+                                                       int* __restrict__ deg) {
+    constexpr int MAXNB = 16;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
+    const int k = key_s[r];
+    const int2 mine = ev2[r];
+    const int me = mine.x, ts = mine.y;
+    const int x = k % W, y = (k / W) % H, plane_base = k - x - W * y;
+    int nb[MAXNB], stp[MAXNB];
+#pragma unroll
+    for (int e = 0; e < MAXNB; ++e) { nb[e] = 0; stp[e] = 0; }
+    nb[0] = r;
+    int nn = 1;
+    for (int i = 0; i < steps && nn < MAXNB; ++i) {
+        int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+        if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
+        int p = plane_base + xn + W * yn;
+        int st = (int)start[p], en = (int)start[p + 1];
+        int lo = max(st, en - Q);
+        for (int s = en - 1; s >= lo; --s) {
+            const int2 c = ev2[s];                               // {id, t} in one 8-byte load
+            if (me > c.x) {
+                if ((float)(ts - c.y) > (float)dt_max) { if (monotone) break; else continue; }
+#pragma unroll
+                for (int e = 1; e < MAXNB; ++e) if (e == nn) { nb[e] = s; stp[e] = i; }
+                if (++nn >= MAXNB) break;
+            }
+        }
+    }
+    int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
+    rp[0] = make_int4(nb[0], nb[1], nb[2], nb[3]); rp[1] = make_int4(nb[4], nb[5], nb[6], nb[7]);
+    rp[2] = make_int4(nb[8], nb[9], nb[10], nb[11]); rp[3] = make_int4(nb[12], nb[13], nb[14], nb[15]);
+    uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
+    sp4[0] = make_uint4(stp[0] | stp[1] << 16, stp[2] | stp[3] << 16, stp[4] | stp[5] << 16, stp[6] | stp[7] << 16);
+    sp4[1] = make_uint4(stp[8] | stp[9] << 16, stp[10] | stp[11] << 16, stp[12] | stp[13] << 16, stp[14] | stp[15] << 16);
+    deg[r] = nn;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged edge search.  The thread-per-event kernels above are bound by divergence-amplified memory
+// round trips (every spiral step is a dependent load chain and a wave pays the longest chain of its 64
+// lanes: ~200 round trips per wave at C2).  Here one wave owns a strip of SW pixels of one sensor row:
+// it stages the pixel-CSR offsets of the strip's (2R+1) x (SW+2R) window and the {id,t} entries of those
+// pixels (2R+1 contiguous ranges of the sorted event array) in LDS with coalesced loads, then every
+// event of the strip walks its spiral against LDS only.  Strips whose window holds more than ELL_CAP
+// entries read the entries from global memory instead (same code path, uniform branch).
+// Optionally marks the pool1 neighbour bitmap per edge (voxel coordinates staged in LDS too).
+#define ELL_CAP 1024
+template <bool MARK>
+__global__ __launch_bounds__(64) void k_build_ell_strip(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+                                                        const unsigned* __restrict__ start, const int16_t* __restrict__ spiral,
+                                                        const unsigned* flags_in, int W, int H, int R, int SW, int steps, int Q,
+                                                        int dt_max, int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
+                                                        int* __restrict__ deg, const int* __restrict__ node_slot,
+                                                        const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
+                                                        unsigned* flags) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+    constexpr int MAXNB = 16;
+    const int D = 2 * R + 1, cols = SW + 2 * R + 1;          // offsets per window row (one more than pixels)
+    int* s_off = s_dyn;                                       // [D][cols]
+    int* s_pre = s_off + D * cols;                            // [D+1] LDS position of each window row's entries
+    int2* s_ev = (int2*)(s_pre + ((D + 1 + 3) & ~3));         // [ELL_CAP]
+    int* s_vox = (int*)(s_ev + ELL_CAP);                      // [ELL_CAP] (MARK only)
+    const int lane = threadIdx.x;
+    const int strips = (W + SW - 1) / SW;
+    const int strip = blockIdx.x % strips, rowid = blockIdx.x / strips;     // rowid = y + H*b
+    const int y = rowid % H, xa = strip * SW, xb = min(xa + SW, W);
+    const int plane_base = (rowid - y) * W;                                  // W*H*b
+    const int own0 = (int)start[plane_base + W * y + xa], own1 = (int)start[plane_base + W * y + xb];
+    if (own1 == own0) return;                                                // no events in this strip
+    for (int t = lane; t < D * cols; t += 64) {
+        int j = t / cols, i = t % cols, yy = y + j - R;
+        int xx = min(max(xa - R + i, 0), W);
+        s_off[t] = (yy >= 0 && yy < H) ? (int)start[plane_base + W * yy + xx] : 0;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int acc = 0;
+        for (int j = 0; j < D; ++j) { s_pre[j] = acc; acc += s_off[j * cols + cols - 1] - s_off[j * cols]; }
+        s_pre[D] = acc;
+    }
+    __syncthreads();
+    const bool staged = s_pre[D] <= ELL_CAP;
+    if (staged) {
+        for (int j = 0; j < D; ++j) {
+            int g0 = s_off[j * cols], len = s_off[j * cols + cols - 1] - g0, p0 = s_pre[j];
+            for (int t = lane; t < len; t += 64) {
+                s_ev[p0 + t] = ev2[g0 + t];
+                if (MARK) s_vox[p0 + t] = node_vox[g0 + t];
+            }
+        }
+    }
+    __syncthreads();
+    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
+    for (int r = own0 + lane; r < own1; r += 64) {
+        const int2 mine = staged ? s_ev[s_pre[R] + (r - s_off[R * cols])] : ev2[r];
+        const int me = mine.x, ts = mine.y;
+        const int x = key_s[r] % W;
+        const int my_slot = MARK ? node_slot[r] : 0;
+        const int my_vox = MARK ? (staged ? s_vox[s_pre[R] + (r - s_off[R * cols])] : node_vox[r]) : 0;
+        int* row = ell_src + (size_t)r * MAXNB;
+        uint16_t* srow = ell_step + (size_t)r * MAXNB;
+        row[0] = r; srow[0] = 0;
+        int nn = 1;
+        for (int i = 0; i < steps && nn < MAXNB; ++i) {
+            const int dx = c_spiral[2 * i], dy = c_spiral[2 * i + 1];
+            const int j = dy + R, c = x - (xa - R) + dx;                     // window row / column of the neighbour pixel
+            const int st = s_off[j * cols + c], en = s_off[j * cols + c + 1];
+            const int lo = max(st, en - Q);
+            const int rel = s_pre[j] - s_off[j * cols];                      // LDS index = global position + rel
+            for (int sp = en - 1; sp >= lo; --sp) {
+                const int2 cnd = staged ? s_ev[sp + rel] : ev2[sp];
+                if (me > cnd.x) {
+                    if ((float)(ts - cnd.y) > (float)dt_max) { if (monotone) break; else continue; }
+                    row[nn] = sp; srow[nn] = (uint16_t)i;
+                    if (MARK) evad_mark_edge_packed(staged ? s_vox[sp + rel] : node_vox[sp], my_vox, my_slot, bitmap, flags);
+                    if (++nn >= MAXNB) break;
+                }
+            }
+        }
+        deg[r] = nn;
+    }
+}
+
 extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                                  const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
                                  int32_t* deg, const int32_t* node_slot, const int32_t* node_vox, int nx, int ny,
-                                 uint32_t* bitmap, void* stream) {
+                                 uint32_t* bitmap, int strip_width, void* stream) {
     if (!sid || !ts_s || !key_s || !pix_start || !counters || !ell_src || !ell_step || !deg || N < 0 || B <= 0 ||
         W <= 0 || H <= 0 || radius_px < 0 || max_num_neighbors < 1 || max_num_neighbors > 65535 || queue_size < 1 ||
         (bitmap && (!node_slot || !node_vox || nx <= 0 || ny <= 0 || nx > 255 || ny > 255)))
@@ -530,7 +669,23 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
     int steps;
     if (ensure_spiral(radius_px, st, &steps)) return -2;
     if (steps > 65535) return EVAD_ERR_ARG;
-    if (max_num_neighbors == 16 && ev2)
+    if (max_num_neighbors == 16 && ev2 && strip_width > 0 && radius_px <= SPIRAL_MAX_R) {
+        int R = radius_px, D = 2 * R + 1, cols = strip_width + 2 * R + 1;
+        size_t lds = sizeof(int) * ((size_t)D * cols + ((D + 1 + 3) & ~3)) + sizeof(int2) * ELL_CAP + (bitmap ? sizeof(int) * ELL_CAP : 0);
+        if (lds > 60 * 1024) return EVAD_ERR_ARG;
+        dim3 grid((unsigned)((long long)B * H * ((W + strip_width - 1) / strip_width)));
+        if (bitmap)
+            hipLaunchKernelGGL(k_build_ell_strip<true>, grid, dim3(64), lds, st, (const int2*)ev2, key_s, pix_start, g_spiral_dev,
+                               counters, W, H, R, strip_width, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
+                               node_vox, bitmap, counters);
+        else
+            hipLaunchKernelGGL(k_build_ell_strip<false>, grid, dim3(64), lds, st, (const int2*)ev2, key_s, pix_start, g_spiral_dev,
+                               counters, W, H, R, strip_width, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
+                               node_vox, bitmap, counters);
+    } else if (max_num_neighbors == 16 && ev2 && strip_width < 0 && !bitmap && radius_px <= SPIRAL_MAX_R)
+        hipLaunchKernelGGL(k_build_ell_reg, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N,
+                           W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg);
+    else if (max_num_neighbors == 16 && ev2)
         hipLaunchKernelGGL(k_build_ell_g, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
                            g_spiral_dev, counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
                            node_vox, bitmap, counters);

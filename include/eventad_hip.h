@@ -68,11 +68,14 @@ int eventad_sort_events(const float* pos, const int64_t* batch, const float* pol
 /* eventad_build_ell: the edge search of ev_graph.cu:15-80 over the pixel CSR.  ELL adjacency in
  * pixel-sorted numbering: ell_src i32[N,K] (slot 0 = self edge), ell_step u16[N,K] (spiral step =
  * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
- * the source-voxel bit in the destination voxel's pool1 neighbour bitmap u32[S,3] (= eventad_pool_edges_mark_ell). */
+ * the source-voxel bit in the destination voxel's pool1 neighbour bitmap u32[S,3] (= eventad_pool_edges_mark_ell).
+ * strip_width (needs ev2): > 0 LDS-staged search, one wave per strip of that many pixels of a sensor row;
+ * < 0 thread per event with the row kept in registers; 0 batched prefetch.  All variants give identical rows. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                       int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step, int32_t* deg,
-                      const int32_t* node_slot, const int32_t* node_vox, int nx, int ny, uint32_t* bitmap, void* stream);
+                      const int32_t* node_slot, const int32_t* node_vox, int nx, int ny, uint32_t* bitmap, int strip_width,
+                      void* stream);
 /* ELL -> the reference's edge buffer layout (i64[2,K], event numbering, -1 padded). */
 int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32_t* sid, int N, int max_num_neighbors,
                          int64_t K, int64_t* edges, void* stream);

@@ -31,22 +31,31 @@ def timeit(fn, it=30):
     return a.elapsed_time(b) / it * 1e3
 
 
-def ell(bitmap):
+def ell(bitmap, sw=0):
     call("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["key_s"]), ptr(ws["pix_start"]),
          ptr(ws["counters"]), N, B, g.W, g.H, g.radius_px, g.delta_t_us, 16, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]),
-         ptr(ws["deg"]), ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1], bitmap, st)
+         ptr(ws["deg"]), ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1], bitmap, sw, st)
 
 
 def ell_old():
     call("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), None, ptr(ws["key_s"]), ptr(ws["pix_start"]),
          ptr(ws["counters"]), N, B, g.W, g.H, g.radius_px, g.delta_t_us, 16, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]),
-         ptr(ws["deg"]), None, None, g.grid[0][0], g.grid[0][1], None, st)
+         ptr(ws["deg"]), None, None, g.grid[0][0], g.grid[0][1], None, 0, st)
 
 
 print("N", N, "E", int(ws["deg"].sum()), "max deg", int(ws["deg"].max()), "deg==16 frac", float((ws["deg"] == 16).float().mean()))
 print("build_ell batched + mark : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap))))
 print("build_ell batched no mark: %.1f us" % timeit(lambda: ell(None)))
 print("build_ell reference-style: %.1f us" % timeit(ell_old))
+ref_src, ref_deg = ws["ell_src"].clone(), ws["deg"].clone()
+t = timeit(lambda: ell(None, -1))
+ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
+print("build_ell register rows  : %.1f us  (matches %s)" % (t, ok))
+for sw in (16, 32, 64, 128):
+    t = timeit(lambda: ell(None, sw))
+    ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
+    print("build_ell LDS strip SW=%3d : %.1f us  (matches %s)" % (sw, t, ok))
+    print("           + fused mark   : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), sw)))
 L = ws["levels"][0]
 print("mark_ell separate        : %.1f us" % timeit(lambda: call("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]),
       ptr(ws["node_slot0"]), N, 16, L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)))
