@@ -28,6 +28,8 @@ __device__ __forceinline__ float4 matvec4(const float (&x)[CINP], const float* _
         float4 wv = *(const float4*)(w + k * 16);
         m.x = fmaf(x[k], wv.x, m.x); m.y = fmaf(x[k], wv.y, m.y);
         m.z = fmaf(x[k], wv.z, m.z); m.w = fmaf(x[k], wv.w, m.w);
+        // keep at most 4 LDS reads in flight: unbounded hoisting of the 20 ds_read_b128 costs 80 VGPRs and spills
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     return m;
 }
@@ -58,35 +60,39 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
     const int node = blockIdx.x * (L1_THREADS / 4) + (threadIdx.x >> 2);
     if (node >= N) return;
     const int d = deg[node];
-    // the whole ELL row up front (16 sources = 64 B, 16 cells = 32 B): the neighbour gathers below no
-    // longer wait on an index load, and the next neighbour's row is fetched while this one is multiplied
-    int src[16]; int cell[16];
+    // the whole ELL row up front (16 sources = 64 B, 16 cells = 32 B, kept packed): the neighbour gathers
+    // below no longer wait on an index load, and while one neighbour row is multiplied the next one is
+    // already in flight in the other register buffer (two buffers, alternating: no copies)
+    int src[16]; unsigned cellp[8];
     {
         const int4* sp = (const int4*)(ell_src + (size_t)node * 16);
         const uint4* cp = (const uint4*)(ell_step + (size_t)node * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { int4 v = sp[q]; src[4 * q] = v.x; src[4 * q + 1] = v.y; src[4 * q + 2] = v.z; src[4 * q + 3] = v.w; }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            uint4 v = cp[q];
-            cell[8 * q] = v.x & 0xffff; cell[8 * q + 1] = v.x >> 16; cell[8 * q + 2] = v.y & 0xffff; cell[8 * q + 3] = v.y >> 16;
-            cell[8 * q + 4] = v.z & 0xffff; cell[8 * q + 5] = v.z >> 16; cell[8 * q + 6] = v.w & 0xffff; cell[8 * q + 7] = v.w >> 16;
-        }
+        for (int q = 0; q < 2; ++q) { uint4 v = cp[q]; cellp[4 * q] = v.x; cellp[4 * q + 1] = v.y; cellp[4 * q + 2] = v.z; cellp[4 * q + 3] = v.w; }
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float x[CINP], xn[CINP];
-    load_row<CINP>(xin + (size_t)node * CINP, xn);         // slot 0 is the self edge: src[0] == node
+    float xa[CINP], xb[CINP];
+    load_row<CINP>(xin + (size_t)node * CINP, xa);         // slot 0 is the self edge: src[0] == node
+    auto edge = [&](const float (&xv)[CINP], int e) {
+        const int cell = (cellp[e >> 1] >> ((e & 1) * 16)) & 0xffff;
+        float4 m = LUT_IN_LDS ? matvec4<CINP>(xv, s_lut + cell * LS + l4)
+                              : matvec4<CINP>(xv, lut + (size_t)cell * CINP * 16 + l4);
+        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    };
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < 16; e += 2) {
         if (e < d) {
-#pragma unroll
-            for (int k = 0; k < CINP; ++k) x[k] = xn[k];
-            if (e + 1 < 16 && e + 1 < d) load_row<CINP>(xin + (size_t)src[e + 1 < 16 ? e + 1 : 15] * CINP, xn);
-            float4 m = LUT_IN_LDS ? matvec4<CINP>(x, s_lut + cell[e] * LS + l4)
-                                  : matvec4<CINP>(x, lut + (size_t)cell[e] * CINP * 16 + l4);
-            acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+            if (e + 1 < d) load_row<CINP>(xin + (size_t)src[e + 1] * CINP, xb);
+            edge(xa, e);
+            if (e + 1 < d) {
+                if (e + 2 < 16 && e + 2 < d) load_row<CINP>(xin + (size_t)src[e + 2 < 16 ? e + 2 : 15] * CINP, xa);
+                edge(xb, e + 1);
+            }
         }
     }
+    float x[CINP];
     load_row<CINP>(xin + (size_t)node * CINP, x);
     float4 m = matvec4<CINP>(x, s_root + l4);                                 // root weight (spline_conv.py:72-73)
     acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
