@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
 
 
-def build_model(W, H, B, dev, seed=42):
+def build_model(W, H, B, dev, seed=42, live_cnn=False):
     import eventad_amd.compat as compat
     compat.install()
     from config.eventad_config import parse_eventad_args
@@ -39,6 +39,8 @@ def build_model(W, H, B, dev, seed=42):
     dagr = DAGR(args, height=H, width=W).to(dev)
     ema = ModelEMA(dagr)
     sd = weights.random_graph_state(seed)
+    if live_cnn:
+        sd.update(weights.random_cnn_state(seed + 1))
     ema.ema.load_state_dict(sd, strict=False)
     ema.ema.cache_luts(radius=args.radius, height=H, width=W)
     model = EventADModel(ema.ema, x_dim=args.x_dim, h_dim=args.h_dim).to(dev)
@@ -121,9 +123,7 @@ def main():
     from eventad_amd import synthetic
     from eventad_amd.train_step import TrainStep
     W, H, n_ev, B, live = synthetic.CONFIGS[a.config]
-    if live:
-        raise SystemExit("round 1 benches the precomputed-CNN-feature configurations (C2, C5)")
-    args, model, sd = build_model(W, H, B, dev)
+    args, model, sd = build_model(W, H, B, dev, live_cnn=live)
     from dagr.utils.buffers import format_data
     raw = synthetic.make_config_batch(a.config, first_clip=rank * B)        # each rank owns different clips
     data = format_data(raw.clone().to(dev))
@@ -175,8 +175,9 @@ def main():
             "metric": "clips/sec (fwd+bwd)", "value": round(world * B * a.steps / dt, 3), "unit": "clips/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: ROL-shape %dx%d, %d events/clip + precomputed CNN feature maps, batch %d per GPU, "
-                                   "backbone fwd + head fwd/bwd + clip + AdamW" % (a.config, W, H, n_ev, B),
+            "config": {"workload": "%s: ROL-shape %dx%d, %d events/clip + %s, batch %d per GPU, "
+                                   "backbone fwd + head fwd/bwd + clip + AdamW" % (a.config, W, H, n_ev, "live ResNet-50 CNN branch" if live
+                                                                                  else "precomputed CNN feature maps", B),
                        "global_batch": world * B, "events_per_batch_per_gpu": N, "realised_edges_per_gpu": E,
                        "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager", "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
                        "final_loss": round(float(loss), 4)},

@@ -1,0 +1,171 @@
+// eventad_amd/csrc/cnn.hip -- the CNN RGB-feature branch (ResNet-50 trunk + 1x1 reducers) as implicit GEMM.
+//
+// Reference: HookModule.forward over torchvision resnet50 (src/dagr/model/networks/net_img.py:122-134,
+// net.py:41-49): cuDNN convolutions + BatchNorm + ReLU in NCHW.  Here activations are NHWC fp32 and
+// every convolution is one exact-fp32 MFMA GEMM
+//      out[m, co] = epilogue( sum_k A[m, k] * Wk[k, co] ),   m = (b, oh, ow),  k = (kh, kw, ci)
+// whose A operand is never materialised: the loader computes the input address of each (m, k) on the
+// fly (zero outside the image).  Eval-mode BatchNorm is folded into the epilogue's per-channel
+// scale/shift, ReLU and the bottleneck's residual add are fused there too.  Same tile structure as
+// gemm.hip (128x128 or 64x64 block tile, v_mfma_f32_32x32x2_f32, k-major LDS slabs of 16).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CBK 16
+
+struct ConvP {
+    const float* in; const float* w; float* out;
+    const float* bias; const float* scale; const float* shift; const float* residual;
+    int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, relu;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ float As[CBK][BM + 4];
+    __shared__ float Bs[CBK][BN + 4];
+    const int M = p.B * p.OH * p.OW, N = p.Cout, K = p.KH * p.KW * p.Cin;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // every thread stages the same A rows in every slab: decompose them once
+    constexpr int AL = BM * (CBK / 4) / 256;             // float4 loads of A per thread per slab (TM)
+    int a_base[AL], a_ih[AL], a_iw[AL];
+#pragma unroll
+    for (int t = 0; t < AL; ++t) {
+        int row = (tid + t * 256) >> 2, gm = m0 + row;
+        if (gm < M) {
+            int b = gm / (p.OH * p.OW), r2 = gm % (p.OH * p.OW), oh = r2 / p.OW, ow = r2 % p.OW;
+            a_base[t] = b * p.IH * p.IW; a_ih[t] = oh * p.stride - p.pad; a_iw[t] = ow * p.stride - p.pad;
+        } else { a_base[t] = -1; a_ih[t] = 0; a_iw[t] = 0; }
+    }
+    for (int k0 = 0; k0 < K; k0 += CBK) {
+#pragma unroll
+        for (int t = 0; t < AL; ++t) {
+            int f = tid + t * 256, row = f >> 2, kq = (f & 3) * 4, gk = k0 + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_base[t] >= 0 && gk < K) {               // Cin % 4 == 0: the 4 k's share (kh, kw)
+                int kk = gk / p.Cin, ci = gk % p.Cin, kh = kk / p.KW, kw = kk % p.KW;
+                int ih = a_ih[t] + kh, iw = a_iw[t] + kw;
+                if (ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
+                    v = *(const float4*)(p.in + ((size_t)(a_base[t] + ih * p.IW + iw)) * p.Cin + ci);
+            }
+            As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
+        }
+        for (int f = tid; f < CBK * (BN / 4); f += 256) {
+            int kr = f / (BN / 4), nq = (f % (BN / 4)) * 4, gk = k0 + kr, gn = n0 + nq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < K && gn < N) v = *(const float4*)(p.w + (size_t)gk * N + gn);      // Cout % 4 == 0
+            *(float4*)&Bs[kr][nq] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < CBK; kk += 2) {
+            int kr = kk + (lane >> 5), c = lane & 31;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[kr][wm + 32 * i + c];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kr][wn + 32 * j + c];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int gn = n0 + wn + j * 32 + (lane & 31);
+            if (gn >= N) continue;
+            float bi = p.bias ? p.bias[gn] : 0.f, sc = p.scale ? p.scale[gn] : 1.f, sh = p.scale ? p.shift[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int gm = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gm >= M) continue;
+                float v = acc[i][j][r] + bi;
+                if (p.scale) v = fmaf(v, sc, sh);
+                if (p.residual) v += p.residual[(size_t)gm * N + gn];
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.out[(size_t)gm * N + gn] = v;
+            }
+        }
+}
+
+/* in f32[B,IH,IW,Cin] (NHWC, Cin % 4 == 0), w f32[KH*KW*Cin, Cout] (k = (kh*KW+kw)*Cin+ci, Cout % 4 == 0),
+ * out f32[B,OH,OW,Cout]; epilogue: +bias, *scale+shift (folded BatchNorm), +residual (same shape as out), ReLU. */
+extern "C" int eventad_conv2d_nhwc(const float* in, const float* w, float* out, const float* bias, const float* scale,
+                                   const float* shift, const float* residual, int B, int IH, int IW, int Cin, int OH,
+                                   int OW, int Cout, int KH, int KW, int stride, int pad, int relu, void* stream) {
+    if (!in || !w || !out || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) ||
+        (Cout & 3) || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || (scale && !shift) ||
+        ((uintptr_t)in & 15) || ((uintptr_t)w & 15))
+        return EVAD_ERR_ARG;
+    ConvP p{in, w, out, bias, scale, shift, residual, B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, relu};
+    long long M = (long long)B * OH * OW;
+    if (M * Cout >= 128ll * 128 * 64 && Cout >= 128)
+        hipLaunchKernelGGL((k_conv_f32<2, 2>), dim3((Cout + 127) / 128, (unsigned)((M + 127) / 128)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((k_conv_f32<1, 1>), dim3((Cout + 63) / 64, (unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    return evad_last_error();
+}
+
+// bn1 + ReLU + 3x3/2 max-pool (pad 1) of the stem, NHWC, one thread per 4 output channels
+__global__ void k_bn_relu_maxpool(const float* __restrict__ in, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  float* __restrict__ out, int B, int IH, int IW, int C, int OH, int OW) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c4 = C / 4;
+    if (t >= (long long)B * OH * OW * c4) return;
+    int c = (int)(t % c4) * 4;
+    long long m = t / c4;
+    int ow = (int)(m % OW), oh = (int)((m / OW) % OH), b = (int)(m / ((long long)OW * OH));
+    float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+    float4 best = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+    for (int dh = 0; dh < 3; ++dh) {
+        int ih = oh * 2 - 1 + dh;
+        if (ih < 0 || ih >= IH) continue;
+        for (int dw = 0; dw < 3; ++dw) {
+            int iw = ow * 2 - 1 + dw;
+            if (iw < 0 || iw >= IW) continue;
+            float4 v = *(const float4*)(in + (((size_t)b * IH + ih) * IW + iw) * C + c);
+            v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+            best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+        }
+    }
+    *(float4*)(out + (size_t)m * C + c) = best;
+}
+
+extern "C" int eventad_bn_relu_maxpool(const float* in, const float* scale, const float* shift, float* out, int B, int IH,
+                                       int IW, int C, int OH, int OW, void* stream) {
+    if (!in || !scale || !shift || !out || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C & 3)) return EVAD_ERR_ARG;
+    long long total = (long long)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(k_bn_relu_maxpool, dim3(evad_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, in, scale, shift, out,
+                       B, IH, IW, C, OH, OW);
+    return evad_last_error();
+}
+
+// image f32[B,3,H,W] (NCHW, already /255 by format_data) -> f32[B,H,W,4] with a zero 4th channel
+__global__ void k_image_to_nhwc4(const float* __restrict__ in, float* __restrict__ out, int B, int HW) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * HW) return;
+    long long b = t / HW; int p = (int)(t % HW);
+    const float* s = in + b * 3 * (long long)HW + p;
+    *(float4*)(out + t * 4) = make_float4(s[0], s[HW], s[2 * (long long)HW], 0.f);
+}
+
+extern "C" int eventad_image_to_nhwc4(const float* in, float* out, int B, int H, int W, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_image_to_nhwc4, dim3(evad_blocks((long long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, in, out, B, H * W);
+    return evad_last_error();
+}

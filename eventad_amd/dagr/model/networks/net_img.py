@@ -1,16 +1,17 @@
 """CNN feature branch: mirror of `dagr.model.networks.net_img.HookModule` over torchvision's
 resnet50 (reference src/dagr/model/networks/net_img.py:42-134, net.py:41-49).
 
-Parameters keep torchvision's key names under `module.` plus `feature_dconv.{0..4}` /
-`output_dconv.{0,1}` so reference checkpoints load.  Only what EventAD consumes is computed:
-the five feature taps (raw conv1 output, layer1..4) through their 1x1 reducers; avgpool/fc and
-`output_dconv` (detection-head inputs, net_img.py:131-133) are skipped.
-ROUND-1 NOTE: the trunk's convolutions run through torch's GPU conv ops (MIOpen) in NHWC; the
-hand-written implicit-GEMM kernels for it are the next step (DESIGN.md 'next').  The bench
-configuration named by BASELINE.json (C2) uses precomputed CNN features and does not run it."""
+The nn.Conv2d / nn.BatchNorm2d modules below only HOLD the parameters under torchvision's key names
+(`module.conv1.weight`, `module.layer1.0.bn1.running_mean`, ..., `feature_dconv.{0..4}`,
+`output_dconv.{0,1}`) so reference checkpoints load; `forward` runs the hand-written NHWC implicit-GEMM
+kernels of csrc/cnn.hip through the C ABI (`NativeCNN`).  Only what EventAD consumes is computed: the
+five feature taps (raw conv1 output, layer1..4) through their 1x1 reducers; avgpool/fc and
+`output_dconv` (detection-head inputs, net_img.py:131-133) are skipped."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ...._lib import call, ptr
 
 BLOCKS = [3, 4, 6, 3]
 PLANES = [64, 128, 256, 512]
@@ -61,16 +62,94 @@ class HookModule(nn.Module):
         self.output_dconv = nn.ModuleList([nn.Conv2d(ci, co, 1) for ci, co in zip(TAPS[3:], output_channels)])
         self.feature_channels = list(feature_channels)
 
+    def train(self, mode=True):
+        self._native = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):                      # .to()/.cuda(): weights move -> rebuild the native images
+        self._native = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._native = None
+        return super().load_state_dict(*a, **k)
+
     @torch.no_grad()
     def forward(self, image):
-        """image f32[B,3,H,W] in [0,1] -> five NHWC feature maps [B,h,w,C] (channels_last views)."""
-        m = self.module
-        x = image.contiguous(memory_format=torch.channels_last)
-        c1 = m.conv1(x)
-        taps = [c1]
-        x = F.max_pool2d(F.relu(m.bn1(c1)), 3, 2, 1)
+        """image f32[B,3,H,W] in [0,1] -> five NHWC feature maps [B,h,w,C]."""
+        if image.device.type != "cuda":
+            raise RuntimeError("HookModule: the CNN branch runs on the GPU only (no CPU fallback)")
+        if getattr(self, "_native", None) is None:
+            object.__setattr__(self, "_native", NativeCNN(self, image.device))
+        return self._native.forward(image)
+
+
+def _fold(bn):
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
+
+
+def _wk(conv, cin_pad=None):
+    """Conv2d weight [Cout,Cin,KH,KW] -> implicit-GEMM operand [KH*KW*Cin, Cout]."""
+    w = conv.weight.detach().float()
+    if cin_pad and cin_pad > w.shape[1]:
+        w = torch.cat([w, torch.zeros(w.shape[0], cin_pad - w.shape[1], *w.shape[2:], device=w.device)], 1)
+    return w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous()
+
+
+class NativeCNN:
+    """Launch sequence of the trunk over csrc/cnn.hip (eval-mode BatchNorm folded into the conv epilogues)."""
+
+    def __init__(self, hook, device):
+        m = hook.module
+        self.dev = device
+        self.stem_w = _wk(m.conv1, 4)
+        self.stem_bn = _fold(m.bn1)
+        self.blocks = []
         for li in range(4):
-            x = getattr(m, "layer%d" % (li + 1))(x)
-            taps.append(x)
-        feats = [d(t) for d, t in zip(self.feature_dconv, taps)]
-        return [f.permute(0, 2, 3, 1).contiguous() for f in feats]
+            for blk in getattr(m, "layer%d" % (li + 1)):
+                d = dict(w1=_wk(blk.conv1), bn1=_fold(blk.bn1), w2=_wk(blk.conv2), bn2=_fold(blk.bn2), w3=_wk(blk.conv3),
+                         bn3=_fold(blk.bn3), stride=blk.conv2.stride[0], planes=blk.conv1.out_channels, tap=False, wd=None)
+                if blk.downsample is not None:
+                    d["wd"], d["bnd"] = _wk(blk.downsample[0]), _fold(blk.downsample[1])
+                self.blocks.append(d)
+            self.blocks[-1]["tap"] = True
+        self.red = [(_wk(c), c.bias.detach().float().contiguous()) for c in hook.feature_dconv]
+        self._key = None
+
+    def _conv(self, x, w, B, IH, IW, Cin, Cout, K, stride, pad, bias=None, bn=None, residual=None, relu=0, out=None):
+        OH, OW = (IH + 2 * pad - K) // stride + 1, (IW + 2 * pad - K) // stride + 1
+        if out is None:
+            out = torch.empty((B, OH, OW, Cout), device=self.dev)
+        call("eventad_conv2d_nhwc", ptr(x), ptr(w), ptr(out), ptr(bias), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
+             ptr(residual), B, IH, IW, Cin, OH, OW, Cout, K, K, stride, pad, relu, torch.cuda.current_stream().cuda_stream)
+        return out, OH, OW
+
+    def forward(self, image):
+        B, _, H, W = image.shape
+        st = torch.cuda.current_stream().cuda_stream
+        image = image.contiguous().float()
+        x0 = torch.empty((B, H, W, 4), device=self.dev)
+        call("eventad_image_to_nhwc4", ptr(image), ptr(x0), B, H, W, st)
+        c1, h, w = self._conv(x0, self.stem_w, B, H, W, 4, 64, 7, 2, 3)                     # hook on `conv1`: raw output
+        taps = [(c1, h, w, 64)]
+        ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        x = torch.empty((B, ph, pw, 64), device=self.dev)
+        call("eventad_bn_relu_maxpool", ptr(c1), ptr(self.stem_bn[0]), ptr(self.stem_bn[1]), ptr(x), B, h, w, 64, ph, pw, st)
+        h, w, cin = ph, pw, 64
+        for d in self.blocks:
+            pl, s = d["planes"], d["stride"]
+            y1, _, _ = self._conv(x, d["w1"], B, h, w, cin, pl, 1, 1, 0, bn=d["bn1"], relu=1)
+            y2, oh, ow = self._conv(y1, d["w2"], B, h, w, pl, pl, 3, s, 1, bn=d["bn2"], relu=1)
+            idt = x
+            if d["wd"] is not None:
+                idt, _, _ = self._conv(x, d["wd"], B, h, w, cin, pl * 4, 1, s, 0, bn=d["bnd"])
+            x, _, _ = self._conv(y2, d["w3"], B, oh, ow, pl, pl * 4, 1, 1, 0, bn=d["bn3"], residual=idt, relu=1)
+            h, w, cin = oh, ow, pl * 4
+            if d["tap"]:
+                taps.append((x, h, w, cin))
+        feats = []
+        for (t, th, tw, tc), (rw, rb) in zip(taps, self.red):
+            f, _, _ = self._conv(t, rw, B, th, tw, tc, rw.shape[1], 1, 1, 0, bias=rb)
+            feats.append(f)
+        return feats

@@ -193,6 +193,19 @@ int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_a
                        double beta2, double eps, double weight_decay, double max_norm, float* partial, float* state,
                        void* stream);
 
+/* ---- (G) CNN feature branch: replaces HookModule.forward over torchvision resnet50 ---------------- */
+/* (reference src/dagr/model/networks/net_img.py:122-134, net.py:41-49).  NHWC fp32 implicit-GEMM convolution
+ * on fp32 MFMA: in f32[B,IH,IW,Cin] (Cin % 4 == 0), w f32[KH*KW*Cin, Cout] with k = (kh*KW+kw)*Cin+ci
+ * (Cout % 4 == 0), out f32[B,OH,OW,Cout]; epilogue +bias, *scale+shift (folded eval BatchNorm), +residual, ReLU. */
+int eventad_conv2d_nhwc(const float* in, const float* w, float* out, const float* bias, const float* scale,
+                        const float* shift, const float* residual, int B, int IH, int IW, int Cin, int OH, int OW,
+                        int Cout, int KH, int KW, int stride, int pad, int relu, void* stream);
+/* stem: bn1 + ReLU + 3x3/2 max-pool (pad 1), NHWC. */
+int eventad_bn_relu_maxpool(const float* in, const float* scale, const float* shift, float* out, int B, int IH, int IW,
+                            int C, int OH, int OW, void* stream);
+/* image f32[B,3,H,W] -> f32[B,H,W,4] (zero 4th channel) so the 7x7 stem reads float4s. */
+int eventad_image_to_nhwc4(const float* in, float* out, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
