@@ -94,7 +94,9 @@ class NativeHead:
         for k, n in (("dS0a", 256), ("dS0b", 256), ("dS1a", 256), ("dS1b", 256), ("dSCa", 32), ("dSCb", 32),
                      ("dHn0", 256), ("dHn1", 256), ("dHnC", 32), ("dSp0", 256), ("dSp1", 256), ("dSpC", 32), ("dX1", 256)):
             w[k] = f(NT, n)
-        w["part"] = [f(3 * 256 * 512) for _ in range(8)]                        # K > 256 slabs, one per grouped problem
+        # slabs for products with K > 256 (one scratch per grouped problem): ceil(K/256) x M x N floats; the largest are
+        # the weight gradients (K = R rows, M x N = 768 x 256) and the chain's [32,768]x[768,256] (3 slabs of 32 x 256)
+        w["part"] = [f(max(3 * 32 * 768, ((R + 255) // 256) * 768 * 256)) for _ in range(8)]
         w["dwatt0"], w["dwatt1"] = f(256), f(256)                               # per-layer accumulators of d soft_attention.weight
         self._B = B
 
@@ -107,6 +109,8 @@ class NativeHead:
             bias = pr[11] if len(pr) > 11 else None
             relu = pr[12] if len(pr) > 12 else 0
             acc = pr[13] if len(pr) > 13 else 0
+            if K > 256 and ((K + 255) // 256) * M * N > self.w["part"][i].numel():
+                raise RuntimeError("grouped GEMM: split-K scratch too small for M=%d N=%d K=%d" % (M, N, K))
             d[16 * i:16 * i + 15] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr() if K > 256 else 0, C.data_ptr(),
                                      bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu]
         call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)

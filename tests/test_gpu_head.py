@@ -141,3 +141,22 @@ def test_grouped_tile_gemm():
     call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
     for pr, ref, shp in zip(probs, refs, shapes):
         assert torch.allclose(pr[3], ref, atol=2e-4, rtol=1e-4), (shp, float((pr[3] - ref).abs().max()))
+
+
+def test_native_head_large_batch_matches_autograd():
+    """B = 32 (R = 1024 rows): the weight-gradient products need 4 split-K slabs -- guards the scratch sizing."""
+    kw = dict(seed=31, num_graphs=32, tracks=10, nodes_per_clip=10, drop_prob=0.1, empty_clip=None, far_box=False)
+    m = _model(31)
+    data = _data(make_head_case(**kw))
+    feats = torch.randn(32, 2, 31, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    labels = data.bbox[:, 4]
+    nh = m.native_head()
+    loss, logits, valid, targets = nh.forward(feats, data.bbox, data.bbox_batch, labels, 32, 256, 256, False)
+    nh.backward()
+    native = {k: v.clone() for k, v in nh.G.items()}
+    loss_t, logits_t, valid_t, _ = m.head(feats, data, labels)
+    loss_t.backward()
+    assert abs(float(loss) - float(loss_t)) < 1e-4 * max(1.0, float(loss_t))
+    for k, p in m.named_parameters():
+        if k in native:
+            assert torch.allclose(native[k], p.grad, atol=5e-5, rtol=5e-4), k
