@@ -35,8 +35,7 @@ class NativeBackbone:
         # edge-search kernel: -1 = thread per event, ELL row in registers (fastest on C2: 130 us); >0 = LDS-staged strips of
         # that many pixels (139 us at 64); 0 = batched prefetch (175 us).  All bit-identical (tools/microbench_ell.py).
         self.strip_width = -1
-        self.fused_mark = False        # measured on C2: reference-style search 141 us + separate marking 98 us beats the
-                                       # batched search with fused marking (222 us); see tools/microbench_ell.py
+        self.fused_mark = True         # pool1 edge bitmap filled by the edge search itself: 172 us vs 134 + 98 us separate (C2)
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
 

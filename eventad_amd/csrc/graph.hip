@@ -525,11 +525,14 @@ __global__ __launch_bounds__(256) void k_build_ell_g(const int2* __restrict__ ev
 // issues ~620 vector-memory instructions per wave, a third of them 2- and 4-byte scattered stores; on
 // CDNA a load's s_waitcnt also waits for every older store (vmcnt counts both), so stores inside the
 // dependent chain lengthen every later round trip.
+template <bool MARK>
 __global__ __launch_bounds__(256) void k_build_ell_reg(const int2* __restrict__ ev2,
                                                        const int* __restrict__ key_s, const unsigned* __restrict__ start,
                                                        const unsigned* flags_in, int N, int W, int H, int steps, int Q,
                                                        int dt_max, int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
-                                                       int* __restrict__ deg) {
+                                                       int* __restrict__ deg, const int* __restrict__ node_slot,
+                                                       const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
+                                                       unsigned* flags) {
     constexpr int MAXNB = 16;
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
@@ -566,6 +569,14 @@ __global__ __launch_bounds__(256) void k_build_ell_reg(const int2* __restrict__ 
     sp4[0] = make_uint4(stp[0] | stp[1] << 16, stp[2] | stp[3] << 16, stp[4] | stp[5] << 16, stp[6] | stp[7] << 16);
     sp4[1] = make_uint4(stp[8] | stp[9] << 16, stp[10] | stp[11] << 16, stp[12] | stp[13] << 16, stp[14] | stp[15] << 16);
     deg[r] = nn;
+    if (MARK) {     // pool1 neighbour bitmap while the row is still in registers (replaces k_mark_ell's second pass)
+        const int my_slot = node_slot[r], my_vox = node_vox[r];
+        int vs[MAXNB];
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[nb[e]] : my_vox;      // independent gathers
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -682,9 +693,14 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
             hipLaunchKernelGGL(k_build_ell_strip<false>, grid, dim3(64), lds, st, (const int2*)ev2, key_s, pix_start, g_spiral_dev,
                                counters, W, H, R, strip_width, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
                                node_vox, bitmap, counters);
-    } else if (max_num_neighbors == 16 && ev2 && strip_width < 0 && !bitmap && radius_px <= SPIRAL_MAX_R)
-        hipLaunchKernelGGL(k_build_ell_reg, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N,
-                           W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg);
+    } else if (max_num_neighbors == 16 && ev2 && strip_width < 0 && radius_px <= SPIRAL_MAX_R) {
+        if (bitmap)
+            hipLaunchKernelGGL(k_build_ell_reg<true>, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
+                               counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        else
+            hipLaunchKernelGGL(k_build_ell_reg<false>, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
+                               counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+    }
     else if (max_num_neighbors == 16 && ev2)
         hipLaunchKernelGGL(k_build_ell_g, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
                            g_spiral_dev, counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
