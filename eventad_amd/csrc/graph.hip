@@ -97,6 +97,7 @@ static int g_spiral_radius = -1;
 // symbol are scalar loads (s_load through the constant cache) instead of 2 vector loads per step.
 #define SPIRAL_MAX_R 13
 __constant__ int16_t c_spiral[2 * (2 * SPIRAL_MAX_R + 1) * (2 * SPIRAL_MAX_R + 1)];
+__constant__ int16_t c_stepof[(2 * SPIRAL_MAX_R + 1) * (2 * SPIRAL_MAX_R + 1)];   // inverse: (dy+R)*D + (dx+R) -> spiral step
 
 static int ensure_spiral(int radius, hipStream_t st, int* steps_out) {
     int steps = (2 * radius + 1) * (2 * radius + 1);
@@ -106,7 +107,15 @@ static int ensure_spiral(int radius, hipStream_t st, int* steps_out) {
         if (g_spiral_dev) hipFree(g_spiral_dev);
         if (hipMalloc(&g_spiral_dev, sizeof(int16_t) * 2 * steps) != hipSuccess) { free(host); return -2; }
         hipMemcpyAsync(g_spiral_dev, host, sizeof(int16_t) * 2 * steps, hipMemcpyHostToDevice, st);
-        if (radius <= SPIRAL_MAX_R) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_spiral), host, sizeof(int16_t) * 2 * steps, 0, hipMemcpyHostToDevice, st);
+        if (radius <= SPIRAL_MAX_R) {
+            hipMemcpyToSymbolAsync(HIP_SYMBOL(c_spiral), host, sizeof(int16_t) * 2 * steps, 0, hipMemcpyHostToDevice, st);
+            int D = 2 * radius + 1;
+            int16_t* inv = (int16_t*)malloc(sizeof(int16_t) * steps);
+            for (int i = 0; i < steps; ++i) inv[(host[2 * i + 1] + radius) * D + host[2 * i] + radius] = (int16_t)i;
+            hipMemcpyToSymbolAsync(HIP_SYMBOL(c_stepof), inv, sizeof(int16_t) * steps, 0, hipMemcpyHostToDevice, st);
+            hipStreamSynchronize(st);
+            free(inv);
+        }
         hipStreamSynchronize(st);
         free(host);
         g_spiral_radius = radius;
@@ -665,6 +674,135 @@ __global__ __launch_bounds__(64) void k_build_ell_strip(const int2* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-parallel edge search: LPE lanes per destination event, one lane per window row.
+// PMC counters on the thread-per-event walk show ~400 dependent vector-memory round trips per wave (a
+// wave pays the longest chain of its 64 lanes at each of the (2R+1)^2 spiral steps) and 79 % of wave
+// time in s_waitcnt.  A window row, however, is ONE contiguous range of the pixel-sorted event array:
+// a lane fetches the 2R+2 pixel-CSR offsets of its row together, then the first 8 {id,t} entries of the
+// row together into LDS, and evaluates the validity rules of ev_graph.cu:56-74 (id < mine, dt <= delta,
+// newest Q per pixel, newest first) from LDS.  The spiral only decides ORDER and the 16-slot cut-off, so
+// it is applied afterwards: per-pixel candidate counts go to LDS indexed by spiral step, an exclusive
+// prefix over the steps gives every pixel its first slot, and a second pass over the (still staged)
+// entries places the sources.  ~3 memory round trips per lane instead of ~400 per wave.
+template <int R, int LPE, bool MARK>
+__global__ __launch_bounds__(64) void k_build_ell_rows(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+                                                       const unsigned* __restrict__ start, const unsigned* flags_in, int N, int W,
+                                                       int H, int Q, int dt_max, int* __restrict__ ell_src,
+                                                       uint16_t* __restrict__ ell_step, int* __restrict__ deg,
+                                                       const int* __restrict__ node_slot, const int* __restrict__ node_vox,
+                                                       unsigned* __restrict__ bitmap, unsigned* flags) {
+    constexpr int D = 2 * R + 1, DD = D * D, EPW = 64 / LPE, SPL = (DD + LPE - 1) / LPE, STG = 8, MAXNB = 16;
+    __shared__ int s_cnt[EPW][DD];
+    __shared__ int2 s_ent[64][STG];
+    __shared__ int s_row[EPW][MAXNB];
+    __shared__ int s_stp[EPW][MAXNB];
+    const int lane = threadIdx.x, g = lane / LPE, sub = lane % LPE;
+    const int ev = blockIdx.x * EPW + g;
+    const bool active = ev < N;
+    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
+    for (int t = sub; t < DD; t += LPE) s_cnt[g][t] = 0;
+    if (sub < MAXNB / (LPE < MAXNB ? 1 : 1)) { for (int t = sub; t < MAXNB; t += LPE) { s_row[g][t] = 0; s_stp[g][t] = 0; } }
+    int me = 0, ts = 0, x = 0, y = 0, plane_base = 0;
+    if (active) {
+        const int k = key_s[ev];
+        const int2 mine = ev2[ev];
+        me = mine.x; ts = mine.y; x = k % W; y = (k / W) % H; plane_base = k - x - W * y;
+    }
+    // ---- this lane's window row: offsets and the first STG entries
+    const int j = sub, yy = y + j - R;
+    const bool row_ok = active && j < D && yy >= 0 && yy < H;
+    int stv[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) stv[i] = 0;
+    if (row_ok) {
+        const int rowb = plane_base + W * yy;
+#pragma unroll
+        for (int i = 0; i <= D; ++i) stv[i] = (int)start[rowb + min(max(x - R + i, 0), W)];
+    }
+    const int rs = stv[0], re = stv[D];
+    int stepv[D];                                            // spiral step of each pixel of this row (fetched together)
+#pragma unroll
+    for (int i = 0; i < D; ++i) stepv[i] = j < D ? c_stepof[j * D + i] : 0;
+#pragma unroll
+    for (int q = 0; q < STG; ++q) if (rs + q < re) s_ent[lane][q] = ev2[rs + q];
+    __syncthreads();
+    auto entry = [&](int s) -> int2 { return (s - rs < STG) ? s_ent[lane][s - rs] : ev2[s]; };
+    // ---- pass 1: number of valid sources per pixel of the row (capped at 15)
+    if (row_ok) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const int st = stv[i], en = stv[i + 1], lo = max(st, en - Q);
+            int c = 0;
+            for (int s = en - 1; s >= lo; --s) {
+                const int2 e = entry(s);
+                if (me > e.x) {
+                    if ((float)(ts - e.y) > (float)dt_max) { if (monotone) break; else continue; }
+                    if (++c >= MAXNB - 1) break;
+                }
+            }
+            s_cnt[g][stepv[i]] = c;
+        }
+    }
+    __syncthreads();
+    // ---- exclusive prefix over the spiral steps (each lane owns SPL consecutive steps)
+    int local = 0;
+#pragma unroll
+    for (int t = 0; t < SPL; ++t) { int q = sub * SPL + t; if (q < DD) local += s_cnt[g][q]; }
+    int incl = local;
+#pragma unroll
+    for (int d2 = 1; d2 < LPE; d2 <<= 1) { int v = __shfl_up(incl, d2, LPE); if (sub >= d2) incl += v; }
+    const int total = __shfl(incl, LPE - 1, LPE);
+    int run = incl - local;
+#pragma unroll
+    for (int t = 0; t < SPL; ++t) { int q = sub * SPL + t; if (q < DD) { int c = s_cnt[g][q]; s_cnt[g][q] = run; run += c; } }
+    __syncthreads();
+    // ---- pass 2: place the sources (slot 0 = self edge)
+    if (row_ok) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const int st = stv[i], en = stv[i + 1], lo = max(st, en - Q);
+            const int step = stepv[i];
+            const int off = 1 + s_cnt[g][step];
+            if (off >= MAXNB) continue;
+            int c = 0;
+            for (int s = en - 1; s >= lo; --s) {
+                const int2 e = entry(s);
+                if (me > e.x) {
+                    if ((float)(ts - e.y) > (float)dt_max) { if (monotone) break; else continue; }
+                    if (off + c < MAXNB) { s_row[g][off + c] = s; s_stp[g][off + c] = step; }
+                    if (++c >= MAXNB - 1 || off + c >= MAXNB) break;
+                }
+            }
+        }
+    }
+    if (active && sub == 0) s_row[g][0] = ev;
+    __syncthreads();
+    if (!active) return;
+    const int nn = min(MAXNB, 1 + total);
+    if (sub < 4) ((int4*)(ell_src + (size_t)ev * MAXNB))[sub] = make_int4(s_row[g][4 * sub], s_row[g][4 * sub + 1], s_row[g][4 * sub + 2], s_row[g][4 * sub + 3]);
+    if (sub < 2) {
+        const int* q = &s_stp[g][8 * sub];
+        ((uint4*)(ell_step + (size_t)ev * MAXNB))[sub] = make_uint4(q[0] | q[1] << 16, q[2] | q[3] << 16, q[4] | q[5] << 16, q[6] | q[7] << 16);
+    }
+    if (sub == 0) deg[ev] = nn;
+    if (MARK) {
+        const int my_slot = node_slot[ev], my_vox = node_vox[ev];
+        for (int e = 1 + sub; e < nn; e += LPE) evad_mark_edge_packed(node_vox[s_row[g][e]], my_vox, my_slot, bitmap, flags);
+    }
+}
+
+template <int R, int LPE>
+static void launch_rows(bool mark, int N, hipStream_t st, const int2* ev2, const int* key_s, const unsigned* start,
+                        const unsigned* counters, int W, int H, int Q, int dt, int* ell_src, uint16_t* ell_step, int* deg,
+                        const int* node_slot, const int* node_vox, unsigned* bitmap, unsigned* flags) {
+    dim3 grid(evad_blocks(N, 64 / LPE));
+    if (mark) hipLaunchKernelGGL((k_build_ell_rows<R, LPE, true>), grid, dim3(64), 0, st, ev2, key_s, start, counters, N, W, H, Q, dt,
+                                 ell_src, ell_step, deg, node_slot, node_vox, bitmap, flags);
+    else      hipLaunchKernelGGL((k_build_ell_rows<R, LPE, false>), grid, dim3(64), 0, st, ev2, key_s, start, counters, N, W, H, Q, dt,
+                                 ell_src, ell_step, deg, node_slot, node_vox, bitmap, flags);
+}
+
 extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                                  const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
@@ -680,7 +818,13 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
     int steps;
     if (ensure_spiral(radius_px, st, &steps)) return -2;
     if (steps > 65535) return EVAD_ERR_ARG;
-    if (max_num_neighbors == 16 && ev2 && strip_width > 0 && radius_px <= SPIRAL_MAX_R) {
+    if (max_num_neighbors == 16 && ev2 && strip_width == -2 && (radius_px == 1 || radius_px == 3 || radius_px == 7 || radius_px == 13)) {
+        const int2* e2 = (const int2*)ev2;
+        if (radius_px == 1)       launch_rows<1, 4>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        else if (radius_px == 3)  launch_rows<3, 8>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        else if (radius_px == 7)  launch_rows<7, 16>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        else                      launch_rows<13, 32>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+    } else if (max_num_neighbors == 16 && ev2 && strip_width > 0 && radius_px <= SPIRAL_MAX_R) {
         int R = radius_px, D = 2 * R + 1, cols = strip_width + 2 * R + 1;
         size_t lds = sizeof(int) * ((size_t)D * cols + ((D + 1 + 3) & ~3)) + sizeof(int2) * ELL_CAP + (bitmap ? sizeof(int) * ELL_CAP : 0);
         if (lds > 60 * 1024) return EVAD_ERR_ARG;
@@ -693,7 +837,7 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
             hipLaunchKernelGGL(k_build_ell_strip<false>, grid, dim3(64), lds, st, (const int2*)ev2, key_s, pix_start, g_spiral_dev,
                                counters, W, H, R, strip_width, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
                                node_vox, bitmap, counters);
-    } else if (max_num_neighbors == 16 && ev2 && strip_width < 0 && radius_px <= SPIRAL_MAX_R) {
+    } else if (max_num_neighbors == 16 && ev2 && strip_width < 0 && radius_px <= SPIRAL_MAX_R) {   // -1, or -2 with an unsupported radius
         if (bitmap)
             hipLaunchKernelGGL(k_build_ell_reg<true>, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
                                counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
