@@ -23,6 +23,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
+# C-ABI call -> kernel name in the rocprofv3 traces / profiles/*_hbm_traffic.json
+KERNEL_OF = {"eventad_build_ell#1": "k_build_ell_reg<true>", "eventad_l1_conv1#1": "k_l1_conv<20, false, true>",
+             "eventad_l1_conv2#1": "k_l1_conv<16, true, true>", "eventad_pool_seg0#1": "k_pool_seg0"}
+
+
+def pmc_traffic(config, kernel):
+    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    rocprofv3 --pmc runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_hbm_traffic.json" % config.lower())), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if kernel in d:
+            return d[kernel]["hbm_bytes_per_launch"], os.path.basename(f)
+    return None, None
 
 
 def build_model(W, H, B, dev, seed=42, live_cnn=False):
@@ -188,8 +205,9 @@ def main():
             name = max(ab, key=lambda k: summ[k][1])
             ms = summ[name][1]
             ach = ab[name] / (ms * 1e-3) / 1e9
+            traffic, src = pmc_traffic(a.config, KERNEL_OF.get(name, ""))
             out["roofline"] = {"bound": "hbm", "kernel": name.split("#")[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                                "algorithmic_bytes": ab[name], "avg_launch_ms": round(ms, 4)}
             out["stage_ms"] = {k.replace("eventad_", ""): round(v[1], 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]}
             out["backbone_ms"] = round(sum(v[1] for v in summ.values()), 4)
