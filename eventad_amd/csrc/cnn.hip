@@ -22,8 +22,9 @@ struct ConvP {
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ float As[CBK][BM + 4];
-    __shared__ float Bs[CBK][BN + 4];
+    constexpr int AL = BM * (CBK / 4) / 256, BL = BN * (CBK / 4) / 256;
+    __shared__ float As[2][CBK][BM + 4];
+    __shared__ float Bs[2][CBK][BN + 4];
     const int M = p.B * p.OH * p.OW, N = p.Cout, K = p.KH * p.KW * p.Cin;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,7 +37,6 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // every thread stages the same A rows in every slab: decompose them once
-    constexpr int AL = BM * (CBK / 4) / 256;             // float4 loads of A per thread per slab (TM)
     int a_base[AL], a_ih[AL], a_iw[AL];
 #pragma unroll
     for (int t = 0; t < AL; ++t) {
@@ -46,41 +46,64 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
             a_base[t] = b * p.IH * p.IW; a_ih[t] = oh * p.stride - p.pad; a_iw[t] = ow * p.stride - p.pad;
         } else { a_base[t] = -1; a_ih[t] = 0; a_iw[t] = 0; }
     }
-    for (int k0 = 0; k0 < K; k0 += CBK) {
+    float4 ra[AL], rb[BL];
+    auto fetch = [&](int k0) {                                 // slab k0 -> registers (global latency hides under MFMAs)
 #pragma unroll
         for (int t = 0; t < AL; ++t) {
-            int f = tid + t * 256, row = f >> 2, kq = (f & 3) * 4, gk = k0 + kq;
+            int f = tid + t * 256, kq = (f & 3) * 4, gk = k0 + kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_base[t] >= 0 && gk < K) {               // Cin % 4 == 0: the 4 k's share (kh, kw)
+            if (a_base[t] >= 0 && gk < K) {                   // Cin % 4 == 0: the 4 k's share (kh, kw)
                 int kk = gk / p.Cin, ci = gk % p.Cin, kh = kk / p.KW, kw = kk % p.KW;
                 int ih = a_ih[t] + kh, iw = a_iw[t] + kw;
                 if (ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
                     v = *(const float4*)(p.in + ((size_t)(a_base[t] + ih * p.IW + iw)) * p.Cin + ci);
             }
-            As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
+            ra[t] = v;
         }
-        for (int f = tid; f < CBK * (BN / 4); f += 256) {
-            int kr = f / (BN / 4), nq = (f % (BN / 4)) * 4, gk = k0 + kr, gn = n0 + nq;
+#pragma unroll
+        for (int t = 0; t < BL; ++t) {
+            int f = tid + t * 256, kr = f / (BN / 4), nq = (f % (BN / 4)) * 4, gk = k0 + kr, gn = n0 + nq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gk < K && gn < N) v = *(const float4*)(p.w + (size_t)gk * N + gn);      // Cout % 4 == 0
-            *(float4*)&Bs[kr][nq] = v;
+            rb[t] = v;
         }
-        __syncthreads();
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < AL; ++t) {
+            int f = tid + t * 256, row = f >> 2, kq = (f & 3) * 4; float4 v = ra[t];
+            As[buf][kq][row] = v.x; As[buf][kq + 1][row] = v.y; As[buf][kq + 2][row] = v.z; As[buf][kq + 3][row] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < BL; ++t) {
+            int f = tid + t * 256, kr = f / (BN / 4), nq = (f % (BN / 4)) * 4;
+            *(float4*)&Bs[buf][kr][nq] = rb[t];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += CBK) {
+        const bool more = k0 + CBK < K;
+        if (more) fetch(k0 + CBK);
 #pragma unroll
         for (int kk = 0; kk < CBK; kk += 2) {
             int kr = kk + (lane >> 5), c = lane & 31;
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kr][wm + 32 * i + c];
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr][wm + 32 * i + c];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kr][wn + 32 * j + c];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr][wn + 32 * j + c];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stage(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -42,13 +42,17 @@ __device__ __forceinline__ float epilogue(float v, int gm, int gn, const GemmEpi
     return v;
 }
 
+// Software pipeline: the global loads of slab k+1 are issued into registers before the MFMAs of slab k
+// and written to the OTHER LDS buffer afterwards, so global latency hides under the 8 x TM x TN MFMAs of a
+// slab and there is one barrier per slab instead of two.
 template <int TM, int TN, bool AT, bool BT>
 __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
                                                   float* __restrict__ C, int ldc, int M, const int* __restrict__ m_dev,
                                                   int N, int K, GemmEpi epi) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ float As[GBK][BM + 4];
-    __shared__ float Bs[GBK][BN + 4];
+    constexpr int AL = BM * (GBK / 4) / 256, BL = BN * (GBK / 4) / 256;     // float4 loads per thread per slab
+    __shared__ float As[2][GBK][BM + 4];
+    __shared__ float Bs[2][GBK][BN + 4];
     if (m_dev) M = min(M, *m_dev);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= M) return;
@@ -61,60 +65,67 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+    float4 ra[AL], rb[BL];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < AL; ++t) {
+            int f = tid + t * 256;
+            ra[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!AT) { int row = f >> 2, kq = (f & 3) * 4, gm = m0 + row, gk = k0 + kq;
+                       if (gm < M) ra[t] = ld4_guard(A + (size_t)gm * lda + gk, gk, K); }
+            else     { int kr = f / (BM / 4), mq = (f % (BM / 4)) * 4, gk = k0 + kr, gm = m0 + mq;
+                       if (gk < K) ra[t] = ld4_guard(A + (size_t)gk * lda + gm, gm, M); }
+        }
+#pragma unroll
+        for (int t = 0; t < BL; ++t) {
+            int f = tid + t * 256;
+            rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!BT) { int kr = f / (BN / 4), nq = (f % (BN / 4)) * 4, gk = k0 + kr, gn = n0 + nq;
+                       if (gk < K) rb[t] = ld4_guard(Bm + (size_t)gk * ldb + gn, gn, N); }
+            else     { int col = f >> 2, kq = (f & 3) * 4, gn = n0 + col, gk = k0 + kq;
+                       if (gn < N) rb[t] = ld4_guard(Bm + (size_t)gn * ldb + gk, gk, K); }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < AL; ++t) {
+            int f = tid + t * 256; float4 v = ra[t];
+            if (!AT) { int row = f >> 2, kq = (f & 3) * 4;
+                       As[buf][kq][row] = v.x; As[buf][kq + 1][row] = v.y; As[buf][kq + 2][row] = v.z; As[buf][kq + 3][row] = v.w; }
+            else     { int kr = f / (BM / 4), mq = (f % (BM / 4)) * 4; *(float4*)&As[buf][kr][mq] = v; }
+        }
+#pragma unroll
+        for (int t = 0; t < BL; ++t) {
+            int f = tid + t * 256; float4 v = rb[t];
+            if (!BT) { int kr = f / (BN / 4), nq = (f % (BN / 4)) * 4; *(float4*)&Bs[buf][kr][nq] = v; }
+            else     { int col = f >> 2, kq = (f & 3) * 4;
+                       Bs[buf][kq][col] = v.x; Bs[buf][kq + 1][col] = v.y; Bs[buf][kq + 2][col] = v.z; Bs[buf][kq + 3][col] = v.w; }
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = 0; k0 < K; k0 += GBK) {
-        // ---- A slab -> As[k][m]
-        if (!AT) {       // stored [M,K]: float4 along k, transposed store
-            for (int f = tid; f < BM * (GBK / 4); f += 256) {
-                int row = f >> 2, kq = (f & 3) * 4;
-                int gm = m0 + row, gk = k0 + kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gm < M) v = ld4_guard(A + (size_t)gm * lda + gk, gk, K);
-                As[kq][row] = v.x; As[kq + 1][row] = v.y; As[kq + 2][row] = v.z; As[kq + 3][row] = v.w;
-            }
-        } else {         // stored [K,M]: float4 along m, direct store
-            for (int f = tid; f < GBK * (BM / 4); f += 256) {
-                int kr = f / (BM / 4), mq = (f % (BM / 4)) * 4;
-                int gk = k0 + kr, gm = m0 + mq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gk < K) v = ld4_guard(A + (size_t)gk * lda + gm, gm, M);
-                *(float4*)&As[kr][mq] = v;
-            }
-        }
-        // ---- B slab -> Bs[k][n]
-        if (!BT) {       // stored [K,N]: float4 along n
-            for (int f = tid; f < GBK * (BN / 4); f += 256) {
-                int kr = f / (BN / 4), nq = (f % (BN / 4)) * 4;
-                int gk = k0 + kr, gn = n0 + nq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gk < K) v = ld4_guard(Bm + (size_t)gk * ldb + gn, gn, N);
-                *(float4*)&Bs[kr][nq] = v;
-            }
-        } else {         // stored [N,K]: float4 along k, transposed store
-            for (int f = tid; f < BN * (GBK / 4); f += 256) {
-                int col = f >> 2, kq = (f & 3) * 4;
-                int gn = n0 + col, gk = k0 + kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gn < N) v = ld4_guard(Bm + (size_t)gn * ldb + gk, gk, K);
-                Bs[kq][col] = v.x; Bs[kq + 1][col] = v.y; Bs[kq + 2][col] = v.z; Bs[kq + 3][col] = v.w;
-            }
-        }
-        __syncthreads();
+        const bool more = k0 + GBK < K;
+        if (more) fetch(k0 + GBK);
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
             int kr = kk + (lane >> 5), c = lane & 31;
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kr][wm + 32 * i + c];
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr][wm + 32 * i + c];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kr][wn + 32 * j + c];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr][wn + 32 * j + c];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stage(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
     // C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
