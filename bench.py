@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap the frozen backbone of batch k+1 with the head update of batch k")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,15 +155,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hipGraph replay is verified on one GPU; capturing an RCCL all-reduce inside a hipGraph could not be tested on
-    # the 1-GPU development box, so multi-rank runs launch eagerly unless EVENTAD_DDP_GRAPH=1 is set.
-    use_graph = not a.no_graph and (world == 1 or os.environ.get("EVENTAD_DDP_GRAPH") == "1")
+    use_graph = not a.no_graph and os.environ.get("EVENTAD_NO_GRAPH") != "1"
+    pipelined = use_graph and not a.no_pipeline
     for _ in range(a.warmup):
         ts.step(data)
     if use_graph:
-        ts.capture(data)
-        run = ts.replay
-    else:
+        try:
+            ts.capture(data, pipelined=pipelined)
+            run = ts.replay
+        except Exception as e:                                 # e.g. a collective that cannot be captured: launch eagerly
+            print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e), file=sys.stderr)
+            torch.cuda.synchronize()
+            use_graph = pipelined = False
+    if not use_graph:
         run = lambda: ts.step(data)
         if not a.no_kernel_timing:
             nb.timing = {}
@@ -196,7 +202,8 @@ def main():
                                    "backbone fwd + head fwd/bwd + clip + AdamW" % (a.config, W, H, n_ev, "live ResNet-50 CNN branch" if live
                                                                                   else "precomputed CNN feature maps", B),
                        "global_batch": world * B, "events_per_batch_per_gpu": N, "realised_edges_per_gpu": E,
-                       "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager", "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
+                       "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
+                       "pipeline": "backbone(batch k+1) || head update(batch k), two streams in one graph" if pipelined else "none", "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
                        "final_loss": round(float(loss), 4)},
         }
         if nb.timing:

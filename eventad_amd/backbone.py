@@ -97,7 +97,7 @@ class NativeBackbone:
             L = Level()
             L.nx, L.ny, L.S, L.C, L.ldx, L.n_max = nx, ny, S, C, ldx, S
             L.feat = i32(S, C); L.sums = torch.empty((S, 2), dtype=torch.int64, device=dev)
-            L.tsum = f32(S); L.cnt = i32(S); L.maxidx = i32(S)
+            L.tsum = torch.empty(S, dtype=torch.float64, device=dev); L.cnt = i32(S); L.maxidx = i32(S)
             L.occ = i32(S + 1); L.slot2node = i32(S); L.bitmap = i32(S, 3)
             L.x = f32(S, ldx); L.npos = f32(S, 3); L.npix = i32(S, 2); L.nbatch = i32(S); L.node_slot = i32(S)
             L.n_dev = torch.zeros(1, dtype=torch.int32, device=dev)

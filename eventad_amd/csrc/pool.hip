@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
     const float* __restrict__ npos, const int* __restrict__ npix, const int* __restrict__ nbatch,
     const int* __restrict__ key_s, const int* __restrict__ nidx, int n_max, const int* __restrict__ n_dev,
     int W, int H, float vsx, float vsy, int nx, int ny, int S,
-    unsigned* __restrict__ feat, unsigned long long* __restrict__ sums, float* __restrict__ tsum,
+    unsigned* __restrict__ feat, unsigned long long* __restrict__ sums, double* __restrict__ tsum,
     unsigned* __restrict__ cnt, int* __restrict__ maxidx, int* __restrict__ node_slot, unsigned* __restrict__ flags) {
     const int n = n_dev ? min(*n_dev, n_max) : n_max;
     const int node = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -80,18 +80,58 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
     if (lane == 0) {
         atomicAdd(&sums[2 * (size_t)slot], (unsigned long long)ipx);
         atomicAdd(&sums[2 * (size_t)slot + 1], (unsigned long long)ipy);
-        atomicAdd(&tsum[slot], pt);
+        // normalised time summed in 2^-40 fixed point: integer adds are order independent (bitwise reproducible)
+        atomicAdd((unsigned long long*)tsum + slot, (unsigned long long)llrintf(pt * 1099511627776.f));
         atomicAdd(&cnt[slot], 1u);
         atomicMax(&maxidx[slot], nidx ? nidx[node] : node);
         node_slot[node] = slot;
     }
 }
 
+// --------------------------------------------------------------------------- mean pooling without float atomics
+// pool4 (mean aggregation, <= 140 input nodes per clip): one wave per output slot scans the input nodes
+// in ascending order and adds the members' rows -- the summation order of the reference's scatter-mean
+// on CPU (sequential index_add_), and bitwise reproducible run to run.  Lane c owns channels c and c+64.
+__global__ __launch_bounds__(256) void k_pool_mean_gather(const float* __restrict__ xa, int lda, int Ca,
+                                                          const float* __restrict__ map, int map_h, int map_w, int Cm,
+                                                          const float* __restrict__ npos, const int* __restrict__ nbatch,
+                                                          const int* __restrict__ node_slot, int n_max,
+                                                          const int* __restrict__ n_dev, int W, int H, int S,
+                                                          float* __restrict__ feat) {
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (slot >= S) return;
+    const int n = min(*n_dev, n_max), C = Ca + Cm;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int i = 0; i < n; ++i) {
+        if (node_slot[i] != slot) continue;
+        for (int c = lane, q = 0; c < C; c += 64, ++q) {
+            float v;
+            if (c < Ca) v = xa[(size_t)i * lda + c];
+            else {
+                int x0, y0; float fx, fy;
+                bilin_setup(npos[3 * i], npos[3 * i + 1], (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+                float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+                bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
+                bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
+                const float* p00 = map + (((size_t)nbatch[i] * map_h + y0) * map_w + x0) * Cm + (c - Ca);
+                v = 0.f;
+                if (vx0 && vy0) v += p00[0] * w00;
+                if (vx1 && vy0) v += p00[Cm] * w01;
+                if (vx0 && vy1) v += p00[(size_t)map_w * Cm] * w10;
+                if (vx1 && vy1) v += p00[(size_t)map_w * Cm + Cm] * w11;
+            }
+            if (q == 0) acc0 += v; else acc1 += v;
+        }
+    }
+    if (lane < C) feat[(size_t)slot * C + lane] = acc0;
+    if (lane + 64 < C) feat[(size_t)slot * C + lane + 64] = acc1;
+}
+
 extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
                                     const float* npos, const int32_t* npix, const int32_t* nbatch, const int32_t* key_s,
                                     const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx,
                                     float vsy, int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums,
-                                    float* tsum, uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags,
+                                    double* tsum, uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags,
                                     void* stream) {
     if (!xa || !npos || !feat || !sums || !tsum || !cnt || !maxidx || !node_slot || !flags || (!key_s && (!npix || !nbatch)) ||
         (Cm > 0 && !map_nhwc) || Ca < 0 || Cm < 0 || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0 || vsx <= 0 || vsy <= 0)
@@ -100,21 +140,26 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
     int S = nx * ny * (B + 1), C = Ca + Cm;
     hipMemsetAsync(feat, 0, sizeof(uint32_t) * (size_t)S * C, st);
     hipMemsetAsync(sums, 0, sizeof(uint64_t) * 2 * (size_t)S, st);
-    hipMemsetAsync(tsum, 0, sizeof(float) * (size_t)S, st);
+    hipMemsetAsync(tsum, 0, sizeof(double) * (size_t)S, st);
     hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)S, st);
     hipMemsetAsync(maxidx, 0xFF, sizeof(int32_t) * (size_t)S, st);
     if (n_max == 0) return evad_last_error();
     dim3 grid(evad_blocks(n_max, 16)), block(256);
-    if (mean_aggr)
-        hipLaunchKernelGGL(k_pool_scatter<true>, grid, block, 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, npix,
+    if (mean_aggr) {
+        if (!n_dev || key_s || C > 128) return EVAD_ERR_ARG;                     // pooled levels only
+        hipLaunchKernelGGL(k_pool_scatter<false>, grid, block, 0, st, xa, lda, 0, map_nhwc, map_h, map_w, 0, npos, npix,
                            nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
                            tsum, cnt, maxidx, node_slot, flags);
+        hipLaunchKernelGGL(k_pool_mean_gather, dim3(evad_blocks(S, 4)), dim3(256), 0, st, xa, lda, Ca, map_nhwc, map_h, map_w,
+                           Cm, npos, nbatch, node_slot, n_max, n_dev, W, H, S, (float*)feat);
+    }
     else
         hipLaunchKernelGGL(k_pool_scatter<false>, grid, block, 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, npix,
                            nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
                            tsum, cnt, maxidx, node_slot, flags);
     return evad_last_error();
 }
+
 
 
 // --------------------------------------------------------------------------- level 0 without atomics
@@ -126,7 +171,7 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     const int* __restrict__ key_s, const int* __restrict__ sid, const int* __restrict__ node_slot,
     const unsigned* __restrict__ pix_start, const int* __restrict__ vx_lo, const int* __restrict__ vy_lo,
     const int* __restrict__ ovf_list, const unsigned* __restrict__ counters, int B, int W, int H, int nx, int ny, int S,
-    float* __restrict__ feat, unsigned long long* __restrict__ sums, float* __restrict__ tsum, unsigned* __restrict__ cnt,
+    float* __restrict__ feat, unsigned long long* __restrict__ sums, unsigned long long* __restrict__ tsum, unsigned* __restrict__ cnt,
     int* __restrict__ maxidx) {
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= S) return;
@@ -134,8 +179,8 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     const int plane = slot / (nx * ny), rem = slot % (nx * ny), cy = rem / nx, cx = rem % nx;
     const float NEG = -__builtin_inff();
     float4 mx = make_float4(NEG, NEG, NEG, NEG);
-    float my = NEG, ts = 0.f;
-    unsigned n = 0; unsigned long long sx = 0, sy = 0; int mi = -1;
+    float my = NEG;
+    unsigned n = 0; unsigned long long sx = 0, sy = 0, ts = 0; int mi = -1;
     auto member = [&](int r) {
         if (node_slot[r] != slot) return;
         float px = posn_s[3 * r], py = posn_s[3 * r + 1];
@@ -157,7 +202,8 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
         add(vx0 && vy1, p00 + (size_t)map_w * 64, w10); add(vx1 && vy1, p00 + (size_t)map_w * 64 + 64, w11);
         mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
         my = fmaxf(my, y2[(size_t)r * 16 + q]);
-        if (q == 0) { ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H); ts += posn_s[3 * r + 2]; mi = max(mi, sid[r]); }
+        if (q == 0) { ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H);
+                      ts += (unsigned long long)llrintf(posn_s[3 * r + 2] * 1099511627776.f); mi = max(mi, sid[r]); }
     };
     if (plane < B) {
         const int x0 = vx_lo[cx], x1 = vx_lo[cx + 1], y0 = vy_lo[cy], y1 = vy_lo[cy + 1];
@@ -189,7 +235,7 @@ extern "C" int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map
                                  const int32_t* key_s, const int32_t* sid, const int32_t* node_slot,
                                  const uint32_t* pix_start, const int32_t* vx_lo, const int32_t* vy_lo,
                                  const int32_t* ovf_list, const uint32_t* counters, int N, int B, int W, int H, int nx,
-                                 int ny, float* feat, uint64_t* sums, float* tsum, uint32_t* cnt, int32_t* maxidx,
+                                 int ny, float* feat, uint64_t* sums, double* tsum, uint32_t* cnt, int32_t* maxidx,
                                  void* stream) {
     if (!y2 || !map_nhwc || !posn_s || !key_s || !sid || !node_slot || !pix_start || !vx_lo || !vy_lo || !ovf_list ||
         !counters || !feat || !sums || !tsum || !cnt || !maxidx || N < 0 || B <= 0 || nx <= 0 || ny <= 0)
@@ -197,7 +243,7 @@ extern "C" int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map
     int S = nx * ny * (B + 1);
     hipLaunchKernelGGL(k_pool_seg0, dim3(evad_blocks(S, 4)), dim3(256), 0, (hipStream_t)stream, y2, map_nhwc, map_h, map_w,
                        posn_s, key_s, sid, node_slot, pix_start, vx_lo, vy_lo, ovf_list, counters, B, W, H, nx, ny, S, feat,
-                       (unsigned long long*)sums, tsum, cnt, maxidx);
+                       (unsigned long long*)sums, (unsigned long long*)tsum, cnt, maxidx);
     return evad_last_error();
 }
 
@@ -210,7 +256,7 @@ __global__ void k_occupancy(const unsigned* __restrict__ cnt, unsigned* __restri
 }
 
 __global__ void k_finalize_nodes(const unsigned* __restrict__ occ_scan, const unsigned* __restrict__ cnt,
-                                 const unsigned long long* __restrict__ sums, const float* __restrict__ tsum,
+                                 const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ tsum,
                                  const int* __restrict__ maxidx, const int* __restrict__ batch_of_index, int S, int level0,
                                  float Wf, float Hf, float whx, float why, int C, int ldx, float* __restrict__ xout,
                                  float* __restrict__ npos, int* __restrict__ npix, int* __restrict__ nbatch,
@@ -228,7 +274,8 @@ __global__ void k_finalize_nodes(const unsigned* __restrict__ occ_scan, const un
     float fx = level0 ? __fdiv_rn(sx, Wf) : __fmul_rn(sx, whx);
     float fy = level0 ? __fdiv_rn(sy, Hf) : __fmul_rn(sy, why);
     float cf = (float)c;
-    float mx = __fdiv_rn(fx, cf), my = __fdiv_rn(fy, cf), mt = __fdiv_rn(tsum[s], cf);
+    float mx = __fdiv_rn(fx, cf), my = __fdiv_rn(fy, cf);
+    float mt = (float)(((double)tsum[s] / 1099511627776.0) / (double)c);
     // round_to_pixel (pooling.py:47-49): floor((p + 1e-5) / wh_inv) * wh_inv
     float qx = floorf(__fdiv_rn(__fadd_rn(mx, 1e-5f), whx)), qy = floorf(__fdiv_rn(__fadd_rn(my, 1e-5f), why));
     float ox = __fmul_rn(qx, whx), oy = __fmul_rn(qy, why);
@@ -251,7 +298,7 @@ __global__ void k_finalize_feat(const unsigned* __restrict__ feat, const unsigne
     xout[(size_t)j * ldx + c] = v;
 }
 
-extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const float* tsum, const uint32_t* cnt,
+extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const double* tsum, const uint32_t* cnt,
                                      const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
                                      int feat_mode, int level0, int W, int H, float wh_inv_x, float wh_inv_y,
                                      uint32_t* occ_scan, uint32_t* scan_tmp, float* xout, int ldx, float* npos_out,
@@ -266,7 +313,7 @@ extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums,
     int rc = evad_exclusive_scan(occ_scan, occ_scan, scan_tmp, S, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_finalize_nodes, dim3(evad_blocks(S, 256)), dim3(256), 0, st, occ_scan, cnt,
-                       (const unsigned long long*)sums, tsum, maxidx, batch_of_index, S, level0, (float)W, (float)H,
+                       (const unsigned long long*)sums, (const unsigned long long*)tsum, maxidx, batch_of_index, S, level0, (float)W, (float)H,
                        wh_inv_x, wh_inv_y, C, ldx, xout, npos_out, npix_out, nbatch_out, node_slot_out, slot2node, n_out_dev);
     dim3 grid(evad_blocks((long long)S * C, 256));
     if (feat_mode == 1)      hipLaunchKernelGGL(k_finalize_feat<1>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);

@@ -96,25 +96,68 @@ class TrainStep:
     # sync, so it can be captured once and replayed -- the launch-bound head chain then costs graph-node
     # boundaries (~1.5 us) instead of Python/ctypes launches.  The captured batch buffers are static:
     # copy a new batch of the same shape into `data` before replay().
-    def capture(self, data, labels=None, warmup=3):
+    def capture(self, data, labels=None, warmup=3, pipelined=False, data_next=None):
+        """Capture one step into a hipGraph.  pipelined=True captures the software-pipelined step below."""
         assert self.native, "graph capture is for the GPU path"
         if labels is None:
             labels = data.bbox[:, 4]
+        body = (lambda: self.pipelined_step(data, labels, data_next or data)) if pipelined else (lambda: self.step(data, labels))
+        if pipelined:
+            self.prime(data)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.step(data, labels)
+                body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._g_loss, self._g_norm = self.step(data, labels)
+        # thread_local: RCCL's watchdog thread polls events while the capture is open
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self._g_loss, self._g_norm = body()
         return self.graph
 
     def replay(self):
         self.graph.replay()
         return self._g_loss, self._g_norm
+
+    # ---- software pipeline across steps.  The DAGR backbone is frozen (models/EventAD.py:148-150), so the
+    # features of batch k+1 do not depend on the head update of batch k: one pipelined step runs
+    #     stream G:  backbone + ROI pooling of batch k+1            (-> feats_next)
+    #     stream H:  head forward/backward + all-reduce + clip/AdamW of batch k   (on feats_cur)
+    # concurrently and then hands feats_next over.  Every batch still gets exactly one backbone pass and one
+    # head update with the weights left by the previous batch -- results are identical to step(); the
+    # launch-bound head chain and the backbone's small kernels simply share the 256 CUs.
+    def prime(self, data):
+        """Fill the pipeline: features of the first batch."""
+        with torch.no_grad():
+            f = self.model.extract_features(data, frames=(1,))
+        if getattr(self, "_feats_cur", None) is None or self._feats_cur.shape != f.shape:
+            self._feats_cur = torch.empty_like(f)
+            self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream()
+        self._feats_cur.copy_(f)
+
+    def pipelined_step(self, data_cur, labels_cur=None, data_next=None):
+        """Head update of `data_cur` (whose features prime()/the previous call produced) overlapped with the
+        backbone of `data_next`.  Returns (loss, grad_norm) of data_cur."""
+        if labels_cur is None:
+            labels_cur = data_cur.bbox[:, 4]
+        data_next = data_next or data_cur
+        main = torch.cuda.current_stream()
+        sg, sh = self._sg, self._sh
+        sg.wait_stream(main); sh.wait_stream(main)
+        with torch.no_grad():
+            with torch.cuda.stream(sg):
+                feats_next = self.model.extract_features(data_next, frames=(1,))
+            with torch.cuda.stream(sh):
+                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data_cur, labels_cur)
+                self.nh.backward()
+                if self.world > 1:
+                    dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
+                norm = self.nh.optimizer_step()
+        main.wait_stream(sg); main.wait_stream(sh)
+        self._feats_cur.copy_(feats_next)
+        return loss, norm
 
     def step_from_feats(self, feats, data, labels=None):
         if labels is None:

@@ -94,13 +94,13 @@ int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t* ell_src, 
                      float* y2, int N, int steps, int max_num_neighbors, void* stream);
 
 /* ---- (D) sampling_skip + Pooling.forward: replaces net.py:15-17,200-228 + pooling.py:51-97 ------ */
-/* Slot table over S = nx*ny*(B+1) voxel slots: feat u32[S,Ca+Cm], sums u64[S,2], tsum f32[S],
+/* Slot table over S = nx*ny*(B+1) voxel slots: feat u32[S,Ca+Cm], sums u64[S,2], tsum 8 bytes[S] (2^-40 fixed point),
  * cnt u32[S], maxidx i32[S].  Level 0 passes key_s (pixel keys) and nidx = sid; pooled levels pass
  * npix/nbatch and n_dev (device-side node count). */
 int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
                          const float* npos, const int32_t* npix, const int32_t* nbatch, const int32_t* key_s,
                          const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx, float vsy,
-                         int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums, float* tsum,
+                         int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums, double* tsum,
                          uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, void* stream);
 /* Level-0 pooling without atomics: one wave per voxel slot walks the slot's pixel rows in the pixel CSR
  * (events of a voxel row are contiguous in sorted order), samples the 64-channel CNN map per member and
@@ -109,9 +109,9 @@ int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc
 int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
                       const int32_t* key_s, const int32_t* sid, const int32_t* node_slot, const uint32_t* pix_start,
                       const int32_t* vx_lo, const int32_t* vy_lo, const int32_t* ovf_list, const uint32_t* counters,
-                      int N, int B, int W, int H, int nx, int ny, float* feat, uint64_t* sums, float* tsum,
+                      int N, int B, int W, int H, int nx, int ny, float* feat, uint64_t* sums, double* tsum,
                       uint32_t* cnt, int32_t* maxidx, void* stream);
-int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const float* tsum, const uint32_t* cnt,
+int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const double* tsum, const uint32_t* cnt,
                           const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
                           int feat_mode /* 0 ordered-uint max, 1 mean, 2 float max */, int level0, int W, int H, float wh_inv_x, float wh_inv_y, uint32_t* occ_scan,
                           uint32_t* scan_tmp, float* xout, int ldx, float* npos_out, int32_t* npix_out,

@@ -108,3 +108,34 @@ def test_live_cnn_branch_matches_oracle():
     got = torch.cat([o for frame in outputs for o in frame], 0).cpu()
     want = torch.cat([o[2] for o in outs], 0).detach()
     assert float((got - want).abs().max()) < 1e-3 and torch.equal(got.argmax(1), want.argmax(1))
+
+
+def test_pipelined_and_graph_steps_equal_sequential_steps():
+    """backbone(k+1) || head(k) on two streams, eagerly and as a replayed hipGraph, must leave exactly the
+    weights that plain sequential steps leave (the backbone is frozen, so the overlap changes nothing)."""
+    from eventad_amd.train_step import TrainStep
+    W = H = 64; B = 3; n = 3000
+    results = []
+    for mode in ("sequential", "pipelined", "graph"):
+        args, model, sd, head_sd, raw, data = _build(W, H, B, n)
+        model.eval()
+        ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
+        if mode == "sequential":
+            for _ in range(4):
+                loss, norm = ts.step(data)
+        elif mode == "pipelined":
+            ts.prime(data)
+            for _ in range(4):
+                loss, norm = ts.pipelined_step(data)
+        else:
+            ts.capture(data, pipelined=True, warmup=1)       # warm-up 1 + capture 0 (capture does not execute) ...
+            for _ in range(3):                               # ... + 3 replays = 4 updates
+                loss, norm = ts.replay()
+        torch.cuda.synchronize()
+        ts.check()
+        results.append(({k: v.clone() for k, v in ts.nh.P.items()}, float(loss), float(norm)))
+    ref = results[0]
+    for got in results[1:]:
+        assert abs(got[1] - ref[1]) < 1e-5 * max(1.0, abs(ref[1])) and abs(got[2] - ref[2]) < 1e-5 * max(1.0, ref[2])
+        for k in ref[0]:
+            assert torch.equal(got[0][k], ref[0][k]), k       # the whole path is free of float atomics: bitwise reproducible
