@@ -102,8 +102,11 @@ __global__ __launch_bounds__(256) void k_pool_mean_gather(const float* __restric
     if (slot >= S) return;
     const int n = min(*n_dev, n_max), C = Ca + Cm;
     float acc0 = 0.f, acc1 = 0.f;
-    for (int i = 0; i < n; ++i) {
-        if (node_slot[i] != slot) continue;
+    for (int base = 0; base < n; base += 64) {              // 64 candidates per step, members found by ballot
+      unsigned long long members = __ballot(base + lane < n && node_slot[base + lane] == slot);
+      while (members) {
+        const int i = base + __ffsll((long long)members) - 1;   // ascending node order = the reference's summation order
+        members &= members - 1;
         for (int c = lane, q = 0; c < C; c += 64, ++q) {
             float v;
             if (c < Ca) v = xa[(size_t)i * lda + c];
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(256) void k_pool_mean_gather(const float* __restric
             }
             if (q == 0) acc0 += v; else acc1 += v;
         }
+      }
     }
     if (lane < C) feat[(size_t)slot * C + lane] = acc0;
     if (lane + 64 < C) feat[(size_t)slot * C + lane + 64] = acc1;
