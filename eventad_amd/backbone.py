@@ -19,6 +19,12 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _rp(t):
+    """Raw pointer of a (possibly strided-view) tensor; the C ABI gets the leading dimension separately."""
+    import ctypes
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
 class Level:
     """Node/edge arrays of one pooled graph level (padded to n_max; valid count in n_dev)."""
     pass
@@ -55,7 +61,7 @@ class NativeBackbone:
         w["wskip"] = spline.pad_rows(sd[p2 + "lin.mlp.weight"].t().contiguous(), 20)
         w["bns"] = spline.fold_bn(sd, p2 + "norm_skip.module.")
         # pooled Layers: X.[W_0..W_24 | root | skip]  and  Y1.[W_0..W_24 | root]
-        self.tail = []
+        self.tail_w = []
         for name, (cin, cout) in list(zip(LAYER_NAMES, LAYER_DIMS))[1:]:
             q1, q2 = "%s%s.conv_block1." % (pre, name), "%s%s.conv_block2." % (pre, name)
             cin_pad = (cin + 3) // 4 * 4
@@ -67,7 +73,7 @@ class NativeBackbone:
                      bn1=[v.to(dev) for v in spline.fold_bn(sd, q1 + "norm.module.")],
                      bn2=[v.to(dev) for v in spline.fold_bn(sd, q2 + "norm.module.")],
                      bns=[v.to(dev) for v in spline.fold_bn(sd, q2 + "norm_skip.module.")])
-            self.tail.append(t)
+            self.tail_w.append(t)
         self.w = {k: ([t.to(dev) for t in v] if isinstance(v, tuple) else v.to(dev)) for k, v in w.items()}
         self.vox_tabs = [t.to(dev).contiguous() for t in g.pixel_voxel_tables()]     # px->cx, py->cy, vx_lo, vy_lo
 
@@ -88,6 +94,29 @@ class NativeBackbone:
             ell_src=i32(N, K), ell_step=torch.empty((N, K), dtype=torch.int16, device=dev), deg=i32(N),
             y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N), node_vox0=i32(N), ovf_list=i32(max(N, 1)),
         )
+        nx0, ny0 = g.grid[0]
+        S0 = nx0 * ny0 * (B + 1)
+        from .synthetic import feature_map_sizes
+        msz = feature_map_sizes(g.W, g.H)[2:]                        # maps 2..4 feed pools 2..4 (tail stage)
+        layout = [("x", S0 * 84, True), ("npos", S0 * 3, True), ("npix", S0 * 2, False), ("nbatch", S0, False),
+                  ("n_dev", 4, False), ("e_dev", 4, False), ("rowptr", S0 + 4, False), ("csr_src", S0 * 75, False),
+                  ("csr_dxy", S0 * 75, False)] + [("map%d" % (k + 2), B * h * w * 64, True) for k, (h, w) in enumerate(msz)]
+        total = sum((n + 3) // 4 * 4 for _, n, _ in layout)
+        hands = []
+        for _ in range(2):
+            flat = torch.zeros(total, dtype=torch.int32, device=dev)
+            H_ = Level(); H_.flat = flat; off = 0
+            for name, n, is_f in layout:
+                v = flat[off:off + n]
+                setattr(H_, name, v.view(torch.float32) if is_f else v)
+                off += (n + 3) // 4 * 4
+            H_.x = H_.x.view(S0, 84); H_.npos = H_.npos.view(S0, 3); H_.npix = H_.npix.view(S0, 2)
+            H_.n_dev = H_.n_dev[:1]; H_.e_dev = H_.e_dev[:1]
+            H_.maps = [getattr(H_, "map%d" % (k + 2)).view(B, h, w, 64) for k, (h, w) in enumerate(msz)]
+            hands.append(H_)
+        ws["hand"] = hands
+        ws["scan_tmp_tail"] = i32(1 << 10)
+        ws["flags_tail"] = torch.zeros(4, dtype=torch.int32, device=dev)     # the tail stage may run concurrently with front
         levels = []
         for lv in range(4):
             nx, ny = g.grid[lv]
@@ -99,10 +128,16 @@ class NativeBackbone:
             L.feat = i32(S, C); L.sums = torch.empty((S, 2), dtype=torch.int64, device=dev)
             L.tsum = torch.empty(S, dtype=torch.float64, device=dev); L.cnt = i32(S); L.maxidx = i32(S)
             L.occ = i32(S + 1); L.slot2node = i32(S); L.bitmap = i32(S, 3)
-            L.x = f32(S, ldx); L.npos = f32(S, 3); L.npix = i32(S, 2); L.nbatch = i32(S); L.node_slot = i32(S)
-            L.n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            L.e_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            L.rowptr = i32(S + 2); L.csr_src = i32(S * 75); L.csr_dxy = i32(S * 75)
+            L.node_slot = i32(S)
+            if lv == 0:                                      # graph of level 0 = the front stage's hand-off (set A)
+                A_ = hands[0]
+                L.x, L.npos, L.npix, L.nbatch, L.n_dev, L.e_dev = A_.x, A_.npos, A_.npix, A_.nbatch, A_.n_dev, A_.e_dev
+                L.rowptr, L.csr_src, L.csr_dxy = A_.rowptr, A_.csr_src, A_.csr_dxy
+            else:
+                L.x = f32(S, ldx); L.npos = f32(S, 3); L.npix = i32(S, 2); L.nbatch = i32(S)
+                L.n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+                L.e_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+                L.rowptr = i32(S + 2); L.csr_src = i32(S * 75); L.csr_dxy = i32(S * 75)
             L.z1 = f32(S, 27 * 64); L.z2 = f32(S, 26 * 64); L.y1 = f32(S, 64); L.y = f32(S, 64)
             L.node_slot_in = i32(S)                          # slot of each of this level's nodes in the NEXT pooling
             levels.append(L)
@@ -130,20 +165,35 @@ class NativeBackbone:
         """pos f32[N,3] normalised (format_data output), polarity f32[N] or [N,1], batch i64[N],
         image_feats: the five CNN feature maps ([B,C,h,w], or [B,h,w,C] if feats_are_nhwc).
         Returns a dict with out3/out4 node arrays (padded) and their device-side counts."""
+        self.front(pos, polarity, batch, num_graphs, image_feats, feats_are_nhwc)
+        return self.tail(self.ws["hand"][0])
+
+    # The forward is two stages with a flat hand-off between them, so that a training loop can overlap
+    # stage `front` of batch k+2, stage `tail` of batch k+1 and the head update of batch k (TrainStep).
+    def front(self, pos, polarity, batch, num_graphs, image_feats, feats_are_nhwc=False):
+        """Event-level stage: sort, edge search, Layer 1, pool1 -> level-0 graph in hand-off set A."""
         g, st = self.geom, _stream()
         self._seq = {}
         N, B = int(pos.shape[0]), int(num_graphs)
         ws = self._alloc(N, B)
+        self._B = B
+        hand = ws["hand"][0]
         pos = pos.contiguous().float()
         polarity = polarity.reshape(-1).contiguous().float()
         batch = batch.contiguous().long()
         maps = []
-        for m in image_feats:
+        for i, m in enumerate(image_feats):
             m = m.contiguous().float()
+            dst = hand.maps[i - 2] if i >= 2 else None     # maps 2..4 travel with the hand-off
             if feats_are_nhwc:
-                maps.append(m)
+                if dst is not None:
+                    dst.copy_(m)
+                maps.append(dst if dst is not None else m)
             else:
-                o = torch.empty((m.shape[0], m.shape[2], m.shape[3], m.shape[1]), dtype=torch.float32, device=m.device)
+                if dst is not None:
+                    assert tuple(dst.shape) == (m.shape[0], m.shape[2], m.shape[3], m.shape[1]), "unexpected CNN map size"
+                o = dst if dst is not None else torch.empty((m.shape[0], m.shape[2], m.shape[3], m.shape[1]),
+                                                            dtype=torch.float32, device=m.device)
                 self._c("eventad_nchw_to_nhwc", ptr(m), ptr(o), m.shape[0], m.shape[1], m.shape[2], m.shape[3], st)
                 maps.append(o)
         assert [m.shape[3] for m in maps] == FEATURE_CHANNELS and all(m.shape[0] == B for m in maps)
@@ -155,7 +205,8 @@ class NativeBackbone:
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
              ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), st)
-        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if (self.fused_mark or self.strip_width) else None, ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
+        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if (self.fused_mark or self.strip_width) else None,
+             ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],
              ptr(ws["levels"][0].bitmap) if self.fused_mark else None, self.strip_width, st)
@@ -164,64 +215,80 @@ class NativeBackbone:
         self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(w["lut2"]), ptr(w["root2"]), ptr(w["bn2"][0]), ptr(w["bn2"][1]), ptr(w["wskip"]), ptr(w["bns"][0]),
              ptr(w["bns"][1]), ptr(ws["y2"]), N, g.steps, K, st)
+        L = ws["levels"][0]
+        fmap = maps[1]
+        # wave-per-voxel segmented max over the pixel CSR (no atomics, no table memsets)
+        self._c("eventad_pool_seg0", ptr(ws["y2"]), ptr(fmap), fmap.shape[1], fmap.shape[2], ptr(ws["posn_s"]),
+                ptr(ws["key_s"]), ptr(ws["sid"]), ptr(ws["node_slot0"]), ptr(ws["pix_start"]), ptr(self.vox_tabs[2]),
+                ptr(self.vox_tabs[3]), ptr(ws["ovf_list"]), ptr(ws["counters"]), N, B, g.W, g.H, L.nx, L.ny,
+                ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), st)
+        self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
+             L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
+             ptr(ws["scan_tmp"]), _rp(hand.x), L.ldx, _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot),
+             ptr(L.slot2node), _rp(hand.n_dev), st)
+        if not self.fused_mark:
+            self._c("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
+                 L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
+        self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.npix), L.n_max,
+             _rp(hand.n_dev), L.nx, L.ny, _rp(hand.rowptr), ptr(ws["scan_tmp"]), _rp(hand.csr_src), _rp(hand.csr_dxy),
+             _rp(hand.e_dev), st)
+        return hand
+
+    def tail(self, hand):
+        """Pooled stage: Layers 2..5 and pools 2..4 on the level-0 graph found in `hand` (set A or B)."""
+        g, st, ws = self.geom, _stream(), self.ws
+        B = self._B
         levels = ws["levels"]
+        L0 = levels[0]
+        # level-0 graph arrays come from the hand-off; everything this stage writes for level 0 is its own
+        G0 = Level()
+        G0.__dict__.update(L0.__dict__)
+        G0.x, G0.npos, G0.npix, G0.nbatch, G0.n_dev, G0.e_dev = hand.x, hand.npos, hand.npix, hand.nbatch, hand.n_dev, hand.e_dev
+        G0.rowptr, G0.csr_src, G0.csr_dxy = hand.rowptr, hand.csr_src, hand.csr_dxy
+        view = [G0] + levels[1:]
+        ws["flags_tail"].zero_()
         out3 = None
         for lv in range(4):
-            L = levels[lv]
-            vsx, vsy = g.voxel[lv]
-            mean = 1 if g.pool_aggr[lv] == "mean" else 0
-            fmap = maps[lv + 1]
-            if lv == 0:
-                # wave-per-voxel segmented max over the pixel CSR (no atomics, no table memsets)
-                self._c("eventad_pool_seg0", ptr(ws["y2"]), ptr(fmap), fmap.shape[1], fmap.shape[2], ptr(ws["posn_s"]),
-                        ptr(ws["key_s"]), ptr(ws["sid"]), ptr(ws["node_slot0"]), ptr(ws["pix_start"]), ptr(self.vox_tabs[2]),
-                        ptr(self.vox_tabs[3]), ptr(ws["ovf_list"]), ptr(ws["counters"]), N, B, g.W, g.H, L.nx, L.ny,
-                        ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), st)
-                boi = ws["bev"]
-            else:
-                Lp = levels[lv - 1]
-                self._c("eventad_pool_scatter", ptr(Lp.y), 64, 64, ptr(fmap), fmap.shape[1], fmap.shape[2], 64,
-                     ptr(Lp.npos), ptr(Lp.npix), ptr(Lp.nbatch), None, None, Lp.n_max, ptr(Lp.n_dev), g.W, g.H, vsx, vsy,
+            L = view[lv]
+            if lv > 0:
+                Lp = view[lv - 1]
+                vsx, vsy = g.voxel[lv]
+                mean = 1 if g.pool_aggr[lv] == "mean" else 0
+                fmap = hand.maps[lv - 1]
+                self._c("eventad_pool_scatter", _rp(Lp.y), 64, 64, _rp(fmap), fmap.shape[1], fmap.shape[2], 64,
+                     _rp(Lp.npos), _rp(Lp.npix), _rp(Lp.nbatch), None, None, Lp.n_max, _rp(Lp.n_dev), g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
-                     ptr(Lp.node_slot_in), ptr(ws["counters"]), st)
-                boi = Lp.nbatch
-            self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(boi),
-                 L.nx, L.ny, B, L.C, 2 if lv == 0 else mean, 1 if lv == 0 else 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
-                 ptr(ws["scan_tmp"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
-                 ptr(L.slot2node), ptr(L.n_dev), st)
-            if lv == 0 and self.fused_mark:
-                pass
-            elif lv == 0:
-                self._c("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
-                     L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
-            else:
-                Lp = levels[lv - 1]
-                self._c("eventad_pool_edges_mark_csr", ptr(Lp.rowptr), ptr(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
-                     ptr(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
-            self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
-                 ptr(L.n_dev), L.nx, L.ny, ptr(L.rowptr), ptr(ws["scan_tmp"]), ptr(L.csr_src), ptr(L.csr_dxy),
-                 ptr(L.e_dev), st)
+                     ptr(Lp.node_slot_in), ptr(ws["flags_tail"]), st)
+                self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), _rp(Lp.nbatch),
+                     L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
+                     ptr(ws["scan_tmp_tail"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
+                     ptr(L.slot2node), ptr(L.n_dev), st)
+                self._c("eventad_pool_edges_mark_csr", _rp(Lp.rowptr), _rp(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
+                     _rp(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["flags_tail"]), st)
+                self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
+                     ptr(L.n_dev), L.nx, L.ny, ptr(L.rowptr), ptr(ws["scan_tmp_tail"]), ptr(L.csr_src), ptr(L.csr_dxy),
+                     ptr(L.e_dev), st)
             # Layer lv+2 on this level's graph
-            t = self.tail[lv]
+            t = self.tail_w[lv]
             dvx, dvy = g.lut_div[lv + 1]
-            self._c("eventad_gemm_f32", ptr(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, ptr(L.n_dev),
+            self._c("eventad_gemm_f32", _rp(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, _rp(L.n_dev),
                  27 * 64, t["cin_pad"], None, None, None, None, 0, 0, st)
-            self._c("eventad_tail_blend", ptr(L.z1), 27 * 64, 25, None, 0, 0, ptr(L.rowptr), ptr(L.csr_src), ptr(L.csr_dxy),
-                 L.n_max, ptr(L.n_dev), dvx, dvy, ptr(t["bn1"][0]), ptr(t["bn1"][1]), None, None, ptr(L.y1), 64, st)
-            self._c("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, ptr(L.n_dev),
+            self._c("eventad_tail_blend", ptr(L.z1), 27 * 64, 25, None, 0, 0, _rp(L.rowptr), _rp(L.csr_src), _rp(L.csr_dxy),
+                 L.n_max, _rp(L.n_dev), dvx, dvy, ptr(t["bn1"][0]), ptr(t["bn1"][1]), None, None, ptr(L.y1), 64, st)
+            self._c("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, _rp(L.n_dev),
                  26 * 64, 64, None, None, None, None, 0, 0, st)
-            self._c("eventad_tail_blend", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, ptr(L.rowptr), ptr(L.csr_src),
-                 ptr(L.csr_dxy), L.n_max, ptr(L.n_dev), dvx, dvy, ptr(t["bn2"][0]), ptr(t["bn2"][1]), ptr(t["bns"][0]),
+            self._c("eventad_tail_blend", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, _rp(L.rowptr), _rp(L.csr_src),
+                 _rp(L.csr_dxy), L.n_max, _rp(L.n_dev), dvx, dvy, ptr(t["bn2"][0]), ptr(t["bn2"][1]), ptr(t["bns"][0]),
                  ptr(t["bns"][1]), ptr(L.y), 64, st)
             if lv == 2:
                 out3 = dict(x=L.y, pos=L.npos, batch=L.nbatch, n_dev=L.n_dev, level=L)
-        L = levels[3]
+        L = view[3]
         out4 = dict(x=L.y, pos=L.npos, batch=L.nbatch, n_dev=L.n_dev, level=L)
         return dict(out3=out3, out4=out4, ws=ws, flags=ws["counters"])
 
     def check_flags(self):
         """Lazy, synchronising check of the data-dependent error flags (fails loudly)."""
-        f = int(self.ws["counters"][0].item())
+        f = int(self.ws["counters"][0].item()) | int(self.ws["flags_tail"][0].item())
         if f & 2:
             raise RuntimeError("eventad_amd: an event lies outside the sensor / batch range")
         if f & 4:

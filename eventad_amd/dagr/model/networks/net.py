@@ -103,14 +103,28 @@ class Net(nn.Module):
                                       self.pooling_dim_at_output)
         return self._native
 
+    def _maps(self, data):
+        feats = getattr(data, "image_feats", None)
+        if feats is not None:
+            return feats, False                              # precomputed CNN features, NCHW like the reference's maps
+        return self.net(data.image), True                    # live CNN branch (NHWC out of csrc/cnn.hip)
+
     @torch.no_grad()
     def forward(self, data, reset=True):
+        self.front(data)
+        return self.tail()
+
+    @torch.no_grad()
+    def front(self, data):
+        """Event-level stage (graph build, Layer 1, pool1) -> level-0 graph in the native hand-off set A."""
         if self._native is None:
             self.prepare(data.pos.device)
-        feats = getattr(data, "image_feats", None)
-        nhwc = False
-        if feats is None:
-            feats, nhwc = self.net(data.image), True
-        res = self._native.forward(data.pos, data.x, data.batch, data.num_graphs, feats, feats_are_nhwc=nhwc)
+        feats, nhwc = self._maps(data)
+        return self._native.front(data.pos, data.x, data.batch, data.num_graphs, feats, feats_are_nhwc=nhwc)
+
+    @torch.no_grad()
+    def tail(self, hand=None):
+        """Pooled stage (Layers 2-5, pools 2-4) on a hand-off set (default: the one front() just wrote)."""
+        res = self._native.tail(hand if hand is not None else self._native.ws["hand"][0])
         self.last = res
         return [GraphOut(res["out3"]), GraphOut(res["out4"])], None

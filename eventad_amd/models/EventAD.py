@@ -124,6 +124,11 @@ class EventADModel(nn.Module):
         self._calls += 1
         self.dagr_model.eval()
         out4 = self.dagr_model.extract_features(data)[1]
+        return self.roi_features(out4, data, frames)
+
+    @torch.no_grad()
+    def roi_features(self, out4, data, frames=(0, 1)):
+        """ROI pooling of the out4 node features per box (EventAD.py:382-397, 406-499) in csrc/roi.hip."""
         B = int(data.num_graphs)
         feats = torch.zeros((B, 2, T, self.x_dim), device=out4.x_padded.device)
         st = torch.cuda.current_stream().cuda_stream

@@ -97,13 +97,21 @@ class TrainStep:
     # boundaries (~1.5 us) instead of Python/ctypes launches.  The captured batch buffers are static:
     # copy a new batch of the same shape into `data` before replay().
     def capture(self, data, labels=None, warmup=3, pipelined=False, data_next=None):
-        """Capture one step into a hipGraph.  pipelined=True captures the software-pipelined step below."""
+        """Capture one step into a hipGraph.  pipelined: False = plain step, True/2 = two-stage pipeline
+        (backbone || head), 3 = three-stage pipeline (front || tail+ROI || head)."""
         assert self.native, "graph capture is for the GPU path"
         if labels is None:
             labels = data.bbox[:, 4]
-        body = (lambda: self.pipelined_step(data, labels, data_next or data)) if pipelined else (lambda: self.step(data, labels))
-        if pipelined:
+        if pipelined == 3:
+            self.prime3(data)
+            body = lambda: self.pipelined_step3(data, labels, data_next or data, data_next or data)
+        elif pipelined:
             self.prime(data)
+            body = lambda: self.pipelined_step(data, labels, data_next or data)
+        else:
+            body = lambda: self.step(data, labels)
+        if False:
+            pass
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -156,6 +164,50 @@ class TrainStep:
                     dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
                 norm = self.nh.optimizer_step()
         main.wait_stream(sg); main.wait_stream(sh)
+        self._feats_cur.copy_(feats_next)
+        return loss, norm
+
+    # ---- three-stage pipeline: front(batch k+2) || tail + ROI(batch k+1) || head update(batch k).
+    # The backbone itself is split at its flat hand-off (eventad_amd/backbone.py): the event-level stage and
+    # the pooled stage are both chains of small dependent launches, so overlapping them hides launch latency.
+    def prime3(self, data):
+        net = self.model.dagr_model.backbone
+        with torch.no_grad():
+            net.front(data)
+            hands = net._native.ws["hand"]
+            hands[1].flat.copy_(hands[0].flat)
+            out4 = net.tail(hands[1])[0][1]
+            f = self.model.roi_features(out4, data, frames=(1,))
+        if getattr(self, "_feats_cur", None) is None or self._feats_cur.shape != f.shape:
+            self._feats_cur = torch.empty_like(f)
+        self._feats_cur.copy_(f)
+        if getattr(self, "_s3", None) is None:
+            self._s3 = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+
+    def pipelined_step3(self, data_cur, labels_cur=None, data_mid=None, data_next=None):
+        """One step of the 3-stage pipeline; returns (loss, grad_norm) of data_cur."""
+        if labels_cur is None:
+            labels_cur = data_cur.bbox[:, 4]
+        data_mid, data_next = data_mid or data_cur, data_next or data_cur
+        net = self.model.dagr_model.backbone
+        hands = net._native.ws["hand"]
+        main = torch.cuda.current_stream()
+        sa, sb, sh = self._s3
+        sa.wait_stream(main); sb.wait_stream(main); sh.wait_stream(main)
+        with torch.no_grad():
+            with torch.cuda.stream(sa):
+                net.front(data_next)
+            with torch.cuda.stream(sb):
+                out4 = net.tail(hands[1])[0][1]
+                feats_next = self.model.roi_features(out4, data_mid, frames=(1,))
+            with torch.cuda.stream(sh):
+                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data_cur, labels_cur)
+                self.nh.backward()
+                if self.world > 1:
+                    dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
+                norm = self.nh.optimizer_step()
+        main.wait_stream(sa); main.wait_stream(sb); main.wait_stream(sh)
+        hands[1].flat.copy_(hands[0].flat)
         self._feats_cur.copy_(feats_next)
         return loss, norm
 
