@@ -125,8 +125,12 @@ class NativeBackbone:
             ldx = C + 4                                      # [features | pos_x | pos_y | 0 0]
             L = Level()
             L.nx, L.ny, L.S, L.C, L.ldx, L.n_max = nx, ny, S, C, ldx, S
-            L.feat = i32(S, C); L.sums = torch.empty((S, 2), dtype=torch.int64, device=dev)
-            L.tsum = torch.empty(S, dtype=torch.float64, device=dev); L.cnt = i32(S); L.maxidx = i32(S)
+            # slot tables back to back (feat | sums | tsum | cnt | maxidx) so the scatter path clears them with ONE memset
+            tab = torch.empty(S * (C + 8), dtype=torch.int32, device=dev)
+            L.feat = tab[: S * C].view(S, C)
+            L.sums = tab[S * C: S * C + 4 * S].view(torch.int64).view(S, 2)
+            L.tsum = tab[S * C + 4 * S: S * C + 6 * S].view(torch.float64)
+            L.cnt = tab[S * C + 6 * S: S * C + 7 * S]; L.maxidx = tab[S * C + 7 * S: S * C + 8 * S]
             L.occ = i32(S + 1); L.slot2node = i32(S); L.bitmap = i32(S, 3)
             L.node_slot = i32(S)
             if lv == 0:                                      # graph of level 0 = the front stage's hand-off (set A)

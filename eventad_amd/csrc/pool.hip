@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
         // normalised time summed in 2^-40 fixed point: integer adds are order independent (bitwise reproducible)
         atomicAdd((unsigned long long*)tsum + slot, (unsigned long long)llrintf(pt * 1099511627776.f));
         atomicAdd(&cnt[slot], 1u);
-        atomicMax(&maxidx[slot], nidx ? nidx[node] : node);
+        atomicMax(&maxidx[slot], (nidx ? nidx[node] : node) + 1);       // stored +1: a zero-filled table means 'none'
         node_slot[node] = slot;
     }
 }
@@ -142,11 +142,18 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int S = nx * ny * (B + 1), C = Ca + Cm;
-    hipMemsetAsync(feat, 0, sizeof(uint32_t) * (size_t)S * C, st);
-    hipMemsetAsync(sums, 0, sizeof(uint64_t) * 2 * (size_t)S, st);
-    hipMemsetAsync(tsum, 0, sizeof(double) * (size_t)S, st);
-    hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)S, st);
-    hipMemsetAsync(maxidx, 0xFF, sizeof(int32_t) * (size_t)S, st);
+    // one memset when the caller laid the tables out back to back (feat | sums | tsum | cnt | maxidx), else five
+    const char* f0 = (const char*)feat; const size_t nf = sizeof(uint32_t) * (size_t)S * C;
+    if ((const char*)sums == f0 + nf && (const char*)tsum == (const char*)sums + 16 * (size_t)S &&
+        (const char*)cnt == (const char*)tsum + 8 * (size_t)S && (const char*)maxidx == (const char*)cnt + 4 * (size_t)S)
+        hipMemsetAsync(feat, 0, nf + 32 * (size_t)S, st);
+    else {
+        hipMemsetAsync(feat, 0, nf, st);
+        hipMemsetAsync(sums, 0, sizeof(uint64_t) * 2 * (size_t)S, st);
+        hipMemsetAsync(tsum, 0, sizeof(double) * (size_t)S, st);
+        hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)S, st);
+        hipMemsetAsync(maxidx, 0, sizeof(int32_t) * (size_t)S, st);
+    }
     if (n_max == 0) return evad_last_error();
     dim3 grid(evad_blocks(n_max, 16)), block(256);
     if (mean_aggr) {
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     const float NEG = -__builtin_inff();
     float4 mx = make_float4(NEG, NEG, NEG, NEG);
     float my = NEG;
-    unsigned n = 0; unsigned long long sx = 0, sy = 0, ts = 0; int mi = -1;
+    unsigned n = 0; unsigned long long sx = 0, sy = 0, ts = 0; int mi = 0;         // mi = max member id + 1
     auto member = [&](int r) {
         if (node_slot[r] != slot) return;
         float px = posn_s[3 * r], py = posn_s[3 * r + 1];
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
         mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
         my = fmaxf(my, y2[(size_t)r * 16 + q]);
         if (q == 0) { ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H);
-                      ts += (unsigned long long)llrintf(posn_s[3 * r + 2] * 1099511627776.f); mi = max(mi, sid[r]); }
+                      ts += (unsigned long long)llrintf(posn_s[3 * r + 2] * 1099511627776.f); mi = max(mi, sid[r] + 1); }
     };
     if (plane < B) {
         const int x0 = vx_lo[cx], x1 = vx_lo[cx + 1], y0 = vy_lo[cy], y1 = vy_lo[cy + 1];
@@ -254,6 +261,34 @@ extern "C" int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map
 // --------------------------------------------------------------------------- finalize
 int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, hipStream_t st);
 
+// occupancy flags + exclusive scan in ONE single-workgroup launch (S <= ~100k slots: 4 launches -> 1)
+__global__ __launch_bounds__(1024) void k_occ_scan_small(const unsigned* __restrict__ cnt, unsigned* __restrict__ out, int S) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < S; base += 1024 * 4) {
+        unsigned v[4], s = 0;
+        int i0 = base + tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < S && cnt[i0 + k] > 0) ? 1u : 0u; s += v[k]; }
+        unsigned inc = s;
+        for (int d = 1; d < 64; d <<= 1) { unsigned t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned wbase = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wv) wbase += wsum[w]; tot += wsum[w]; }
+        unsigned ex = carry_s + wbase + inc - s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < S) out[i0 + k] = ex; ex += v[k]; }
+        __syncthreads();
+        if (tid == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) out[S] = carry_s;
+}
+
 __global__ void k_occupancy(const unsigned* __restrict__ cnt, unsigned* __restrict__ occ, int S) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < S) occ[s] = cnt[s] > 0 ? 1u : 0u;
@@ -285,7 +320,7 @@ __global__ void k_finalize_nodes(const unsigned* __restrict__ occ_scan, const un
     float ox = __fmul_rn(qx, whx), oy = __fmul_rn(qy, why);
     npos[3 * j] = ox; npos[3 * j + 1] = oy; npos[3 * j + 2] = mt;
     npix[2 * j] = (int)qx; npix[2 * j + 1] = (int)qy;
-    nbatch[j] = batch_of_index[maxidx[s]];
+    nbatch[j] = batch_of_index[maxidx[s] - 1];
     xout[(size_t)j * ldx + C] = ox; xout[(size_t)j * ldx + C + 1] = oy;
     for (int k = C + 2; k < ldx; ++k) xout[(size_t)j * ldx + k] = 0.f;
 }
@@ -313,9 +348,13 @@ extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums,
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int S = nx * ny * (B + 1);
-    hipLaunchKernelGGL(k_occupancy, dim3(evad_blocks(S, 256)), dim3(256), 0, st, cnt, occ_scan, S);
-    int rc = evad_exclusive_scan(occ_scan, occ_scan, scan_tmp, S, st);
-    if (rc) return rc;
+    if (S <= 131072) {
+        hipLaunchKernelGGL(k_occ_scan_small, dim3(1), dim3(1024), 0, st, cnt, occ_scan, S);
+    } else {
+        hipLaunchKernelGGL(k_occupancy, dim3(evad_blocks(S, 256)), dim3(256), 0, st, cnt, occ_scan, S);
+        int rc = evad_exclusive_scan(occ_scan, occ_scan, scan_tmp, S, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_finalize_nodes, dim3(evad_blocks(S, 256)), dim3(256), 0, st, occ_scan, cnt,
                        (const unsigned long long*)sums, (const unsigned long long*)tsum, maxidx, batch_of_index, S, level0, (float)W, (float)H,
                        wh_inv_x, wh_inv_y, C, ldx, xout, npos_out, npix_out, nbatch_out, node_slot_out, slot2node, n_out_dev);
@@ -355,6 +394,33 @@ __global__ void k_edge_count(const unsigned* __restrict__ bitmap, const int* __r
     unsigned d = 0;
     if (j < n) { const unsigned* w = bitmap + (size_t)node_slot_out[j] * 3; d = __popc(w[0]) + __popc(w[1]) + __popc(w[2]); }
     degree[j] = d;
+}
+
+// per-destination edge counts + exclusive scan in one single-workgroup launch (small graphs)
+__global__ __launch_bounds__(1024) void k_edge_count_scan_small(const unsigned* __restrict__ bitmap, const int* __restrict__ node_slot_out,
+                                                                int n_max, const int* __restrict__ n_dev, unsigned* __restrict__ rowptr) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = min(*n_dev, n_max), total = n_max + 1;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        int j = base + tid;
+        unsigned d = 0;
+        if (j < n) { const unsigned* w = bitmap + (size_t)node_slot_out[j] * 3; d = __popc(w[0]) + __popc(w[1]) + __popc(w[2]); }
+        unsigned inc = d;
+        for (int dd = 1; dd < 64; dd <<= 1) { unsigned t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned wbase = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wv) wbase += wsum[w]; tot += wsum[w]; }
+        if (j < total) rowptr[j] = carry_s + wbase + inc - d;
+        __syncthreads();
+        if (tid == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (tid == 0) rowptr[total] = carry_s;
 }
 
 __global__ void k_edge_emit(const unsigned* __restrict__ bitmap, const int* __restrict__ node_slot_out,
@@ -417,10 +483,14 @@ extern "C" int eventad_pool_edges_emit(const uint32_t* bitmap, const int32_t* no
         !csr_dxy || !e_out_dev || n_max_out < 0 || nx <= 0 || ny <= 0)
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_edge_count, dim3(evad_blocks(n_max_out + 1, 256)), dim3(256), 0, st, bitmap, node_slot_out,
-                       n_max_out, n_out_dev, rowptr);
-    int rc = evad_exclusive_scan(rowptr, rowptr, scan_tmp, n_max_out + 1, st);
-    if (rc) return rc;
+    if (n_max_out <= 131072) {
+        hipLaunchKernelGGL(k_edge_count_scan_small, dim3(1), dim3(1024), 0, st, bitmap, node_slot_out, n_max_out, n_out_dev, rowptr);
+    } else {
+        hipLaunchKernelGGL(k_edge_count, dim3(evad_blocks(n_max_out + 1, 256)), dim3(256), 0, st, bitmap, node_slot_out,
+                           n_max_out, n_out_dev, rowptr);
+        int rc = evad_exclusive_scan(rowptr, rowptr, scan_tmp, n_max_out + 1, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_edge_emit, dim3(evad_blocks(n_max_out > 0 ? n_max_out : 1, 256)), dim3(256), 0, st, bitmap,
                        node_slot_out, slot2node, npix_out, n_max_out, n_out_dev, nx, ny, rowptr, csr_src, csr_dxy, e_out_dev);
     return evad_last_error();
