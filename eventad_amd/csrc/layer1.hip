@@ -60,36 +60,41 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
     const int node = blockIdx.x * (L1_THREADS / 4) + (threadIdx.x >> 2);
     if (node >= N) return;
     const int d = deg[node];
-    // the whole ELL row up front (16 sources = 64 B, 16 cells = 32 B, kept packed): the neighbour gathers
-    // below no longer wait on an index load, and while one neighbour row is multiplied the next one is
-    // already in flight in the other register buffer (two buffers, alternating: no copies)
-    int src[16]; unsigned cellp[8];
-    {
-        const int4* sp = (const int4*)(ell_src + (size_t)node * 16);
-        const uint4* cp = (const uint4*)(ell_step + (size_t)node * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { int4 v = sp[q]; src[4 * q] = v.x; src[4 * q + 1] = v.y; src[4 * q + 2] = v.z; src[4 * q + 3] = v.w; }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { uint4 v = cp[q]; cellp[4 * q] = v.x; cellp[4 * q + 1] = v.y; cellp[4 * q + 2] = v.z; cellp[4 * q + 3] = v.w; }
-    }
+    // ELL row consumed in quads (int4 of sources + 4 packed cells), the next quad fetched one quad ahead, so the
+    // neighbour gathers never wait on an index load; while one neighbour row is multiplied the next one is
+    // already in flight in the other register buffer (two buffers, alternating: no copies).
+    const int4* sp = (const int4*)(ell_src + (size_t)node * 16);
+    const uint2* cp = (const uint2*)(ell_step + (size_t)node * 16);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float xa[CINP], xb[CINP];
     load_row<CINP>(xin + (size_t)node * CINP, xa);         // slot 0 is the self edge: src[0] == node
-    auto edge = [&](const float (&xv)[CINP], int e) {
-        const int cell = (cellp[e >> 1] >> ((e & 1) * 16)) & 0xffff;
+    auto edge = [&](const float (&xv)[CINP], int cell) {
         float4 m = LUT_IN_LDS ? matvec4<CINP>(xv, s_lut + cell * LS + l4)
                               : matvec4<CINP>(xv, lut + (size_t)cell * CINP * 16 + l4);
         acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
     };
+    int4 sv = sp[0]; uint2 cv = cp[0];
 #pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-        if (e < d) {
-            if (e + 1 < d) load_row<CINP>(xin + (size_t)src[e + 1] * CINP, xb);
-            edge(xa, e);
-            if (e + 1 < d) {
-                if (e + 2 < 16 && e + 2 < d) load_row<CINP>(xin + (size_t)src[e + 2 < 16 ? e + 2 : 15] * CINP, xa);
-                edge(xb, e + 1);
+    for (int q = 0; q < 4; ++q) {
+        const int e0 = 4 * q;
+        if (e0 < d) {
+            int4 svn = sv; uint2 cvn = cv;
+            if (q < 3 && e0 + 4 < d) { svn = sp[q + 1]; cvn = cp[q + 1]; }
+            if (e0 + 1 < d) load_row<CINP>(xin + (size_t)sv.y * CINP, xb);
+            edge(xa, cv.x & 0xffff);
+            if (e0 + 1 < d) {
+                if (e0 + 2 < d) load_row<CINP>(xin + (size_t)sv.z * CINP, xa);
+                edge(xb, cv.x >> 16);
+                if (e0 + 2 < d) {
+                    if (e0 + 3 < d) load_row<CINP>(xin + (size_t)sv.w * CINP, xb);
+                    edge(xa, cv.y & 0xffff);
+                    if (e0 + 3 < d) {
+                        if (q < 3 && e0 + 4 < d) load_row<CINP>(xin + (size_t)svn.x * CINP, xa);
+                        edge(xb, cv.y >> 16);
+                    }
+                }
             }
+            sv = svn; cv = cvn;
         }
     }
     float x[CINP];
