@@ -15,7 +15,10 @@
 #define NT 32          // track slots per clip
 #define FEAT_T 31      // rows of the ROI feature table per (clip, frame)  (reference: max_boxes + 1)
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// v_exp_f32-based forms (relative error ~1e-7, saturate correctly at +-inf): the libm tanhf/expf expand to
+// ~50 instructions each and dominated the attention kernels
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
 
 // ------------------------------------------------------------------------------------------------
 // (clip, track) lookup tables: replaces EventAD.py:229-255 (first matching box row, normalised box,
@@ -70,7 +73,7 @@ __global__ void k_gru_cell_fwd(const float* __restrict__ gi, const float* __rest
     const float* a = gi + (size_t)row * 3 * H; const float* c = gh + (size_t)row * 3 * H;
     float r = sigmoidf_(a[j] + c[j]);
     float z = sigmoidf_(a[H + j] + c[H + j]);
-    float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    float n = tanhf_(a[2 * H + j] + r * c[2 * H + j]);
     float h = hprev[t];
     float hn = (1.f - z) * n + z * h;
     float* g = gates + (size_t)row * 3 * H;
@@ -99,7 +102,7 @@ __global__ void k_gru_cell_fwd_g(CellGroup g) {
     const float* a = P.a + (size_t)row * 3 * H; const float* c = P.b + (size_t)row * 3 * H;        // gi, gh
     float r = sigmoidf_(a[j] + c[j]);
     float z = sigmoidf_(a[H + j] + c[H + j]);
-    float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    float n = tanhf_(a[2 * H + j] + r * c[2 * H + j]);
     float h = P.c[t];                                                                               // hprev
     float hn = (1.f - z) * n + z * h;
     float* gt = P.o0 + (size_t)row * 3 * H;                                                         // gates
@@ -217,7 +220,7 @@ __device__ __forceinline__ void att_fwd_body(const AttProb& P, const int* valid)
 #pragma unroll
     for (int i = 0; i < CH; ++i) hn[i] = P.Hn[base + i];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) part += tanhf(hn[i]) * P.w[c * CH + i];
+    for (int i = 0; i < CH; ++i) part += tanhf_(hn[i]) * P.w[c * CH + i];
     part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
     if (c == 0) s_s[k] = part;
     __syncthreads();
@@ -266,7 +269,7 @@ __device__ __forceinline__ void att_bwd_body(const AttProb& P, const int* valid)
     const float al = s_al[k], ds = v ? al * (s_da[k] - dot) : 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        float th = tanhf(hn[i]);
+        float th = tanhf_(hn[i]);
         if (v) {
             float d = gs[i] * al + ds * P.w[c * CH + i] * (1.f - th * th);
             if (P.dHn_out) d += P.dHn_out[base + i];

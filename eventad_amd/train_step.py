@@ -9,6 +9,8 @@ USED head parameters (852,066 floats = 3.41 MB; fusion_module.attention.* never 
 are summed over ranks in one flat-bucket all-reduce (RCCL over xGMI) before clipping.  Loss is the
 reference's SUM over objects, so summing gradients over ranks equals one large-batch reference step
 with per-rank hidden-state chains."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,6 +24,8 @@ class TrainStep:
             # product path: HIP head + fused clip/AdamW on flat buffers; ONE all-reduce on the flat gradient
             self.nh = model.native_head(lr=lr, weight_decay=weight_decay, grad_clip=grad_clip)
             self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+            if os.environ.get("EVENTAD_FORCE_ALLREDUCE") == "1" and dist.is_initialized():
+                self.world = max(self.world, 2)        # test hook: exercise the collective (and its capture) on one rank
             self.group = process_group
             self.bucket = self.nh.grads
             self.bucket_bytes = 4 * self.nh.n
