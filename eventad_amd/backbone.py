@@ -5,6 +5,7 @@ Host logic only: weight preparation (LUT / concatenated kernel matrices / folded
 workspace ownership (torch tensors = device memory plumbing) and the sequence of C-ABI calls.
 No host<->device synchronisation happens inside `forward`; node and edge counts of the pooled
 graphs stay on the device (`n_dev`), so the whole forward is hipGraph-capturable."""
+import os
 import torch
 
 from . import _lib, spline
@@ -40,7 +41,7 @@ class NativeBackbone:
         self._ws_key = None
         # edge-search kernel: -1 = thread per event, ELL row in registers (fastest on C2: 130 us); >0 = LDS-staged strips of
         # that many pixels (139 us at 64); 0 = batched prefetch (175 us).  All bit-identical (tools/microbench_ell.py).
-        self.strip_width = -1
+        self.strip_width = int(os.environ.get("EVENTAD_ELL_VARIANT", "-1"))   # edge-search kernel, see eventad_build_ell
         self.fused_mark = True         # pool1 edge bitmap filled by the edge search itself: 172 us vs 134 + 98 us separate (C2)
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)

@@ -255,12 +255,16 @@ __global__ void k_prep_events(const float* __restrict__ pos, const long long* __
 }
 
 __global__ void k_scatter_events(const int* __restrict__ key, const unsigned* __restrict__ start,
-                                 unsigned* __restrict__ count, int* __restrict__ sid_tmp, int N) {
+                                 unsigned* __restrict__ count, int* __restrict__ sid_tmp, int N, unsigned* __restrict__ lmax) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= N) { return; }
     int k = key[i];
     unsigned c = atomicSub(&count[k], 1u);               // old value: 1..cnt
     sid_tmp[start[k] + c - 1] = i;
+    // longest pixel segment of the batch (bounds the binary searches of k_build_ell_bf): one atomic per wave
+    unsigned m = c;
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(lmax, m);
 }
 
 // Order every pixel segment by event id (rank placement; ids are unique).  Short segments are
@@ -389,7 +393,7 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     long long P = (long long)B * H * W;
     if (P >= (1ll << 31)) return EVAD_ERR_ARG;
     hipMemsetAsync(pix_count, 0, sizeof(uint32_t) * (P + 1), st);
-    hipMemsetAsync(counters + 1, 0, 2 * sizeof(uint32_t), st);
+    hipMemsetAsync(counters + 1, 0, 3 * sizeof(uint32_t), st);
     if (node_slot && (!px_to_cx || !py_to_cy || !ovf_list || !node_vox || nx <= 0 || ny <= 0 || vsx <= 0 || vsy <= 0)) return EVAD_ERR_ARG;
     if (N > 0)
         hipLaunchKernelGGL(k_prep_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, pos, (const long long*)batch, N, B,
@@ -397,7 +401,7 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     int rc = evad_exclusive_scan(pix_count, pix_start, scan_tmp, P, st);
     if (rc) return rc;
     if (N == 0) return evad_last_error();
-    hipLaunchKernelGGL(k_scatter_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, pix_count, sid_tmp, N);
+    hipLaunchKernelGGL(k_scatter_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, pix_count, sid_tmp, N, counters + 3);
     hipLaunchKernelGGL(k_order_short, dim3(evad_blocks(P, 256)), dim3(256), 0, st, pix_start, sid_tmp, sid, (int)P,
                        long_list, counters + 1);
     hipLaunchKernelGGL(k_order_long, dim3(512), dim3(256), 0, st, pix_start, sid_tmp, sid, long_list, counters + 1);
@@ -803,6 +807,332 @@ static void launch_rows(bool mark, int N, hipStream_t st, const int2* ev2, const
                                  ell_src, ell_step, deg, node_slot, node_vox, bitmap, flags);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-per-event edge search: lanes = spiral steps.
+// With timestamps non-decreasing in id (checked on the device: EVAD_FLAG_T_NOT_MONOTONE) the valid
+// sources of one neighbour pixel are a CONTIGUOUS range of its id-sorted segment: ids below mine form a
+// prefix, entries inside the time window a suffix of that prefix, the FIFO depth another suffix.  A lane
+// therefore finds its pixel's range [lo, hi) with two binary searches (no data-dependent walk), a wave
+// scan over the 64 lanes turns the per-pixel counts into ELL slot offsets in spiral order, and each lane
+// writes its <= 15 sources newest first.  Radii beyond 3 (more than 64 steps) take further rounds of 64
+// steps and stop as soon as the row is full -- dense scenes finish in the first round.  No lane ever loops
+// over another lane's data, so the divergence cost of the thread-per-event walk (a wave paying the longest
+// FIFO walk of its lanes at each of (2R+1)^2 steps) disappears.
+// Non-monotone input falls back, per lane, to the reference's linear scan of the newest Q entries.
+template <bool MARK>
+__global__ __launch_bounds__(256) void k_build_ell_wave(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+                                                        const unsigned* __restrict__ start, const unsigned* flags_in, int N, int W,
+                                                        int H, int steps, int Q, int dt_max, int* __restrict__ ell_src,
+                                                        uint16_t* __restrict__ ell_step, int* __restrict__ deg,
+                                                        const int* __restrict__ node_slot, const int* __restrict__ node_vox,
+                                                        unsigned* __restrict__ bitmap, unsigned* flags) {
+    constexpr int MAXNB = 16;
+    const int lane = threadIdx.x & 63;
+    const int ev = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ev >= N) return;
+    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
+    const int k = key_s[ev];
+    const int2 mine = ev2[ev];
+    const int me = mine.x, ts = mine.y;
+    const int x = k % W, y = (k / W) % H, plane_base = k - x - W * y;
+    const int my_slot = MARK ? node_slot[ev] : 0, my_vox = MARK ? node_vox[ev] : 0;
+    int* row = ell_src + (size_t)ev * MAXNB;
+    uint16_t* srow = ell_step + (size_t)ev * MAXNB;
+    if (lane == 0) { row[0] = ev; srow[0] = 0; }
+    int filled = 1;                                          // wave-uniform: slots used so far
+    for (int i0 = 0; i0 < steps && filled < MAXNB; i0 += 64) {
+        const int i = i0 + lane;
+        int hi = 0, cnt = 0;
+        if (i < steps) {
+            const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+            if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
+                const int p = plane_base + xn + W * yn;
+                const int st = (int)start[p], en = (int)start[p + 1];
+                const int lo0 = max(st, en - Q);             // the FIFO keeps the newest Q ids of the pixel
+                if (en > lo0) {
+                    if (monotone) {
+                        int a = lo0, b = en;                  // hi = first position with id >= mine
+                        while (a < b) { int m = (a + b) >> 1; if (ev2[m].x < me) a = m + 1; else b = m; }
+                        hi = a;
+                        a = lo0; b = hi;                      // lo = first position with ts - t <= dt_max
+                        while (a < b) { int m = (a + b) >> 1; if (ts - ev2[m].y > dt_max) a = m + 1; else b = m; }
+                        cnt = min(hi - a, MAXNB - 1);
+                    } else {                                  // exact reference scan (ev_graph.cu:51-76), count only
+                        for (int s = en - 1; s >= lo0 && cnt < MAXNB - 1; --s) {
+                            const int2 c = ev2[s];
+                            if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) ++cnt;
+                        }
+                        hi = en; cnt = cnt;
+                    }
+                }
+            }
+        }
+        int incl = cnt;                                       // inclusive scan over the lanes = spiral order
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+        const int total = __shfl(incl, 63, 64);
+        int slot = filled + incl - cnt;
+        if (cnt > 0 && slot < MAXNB) {
+            if (monotone) {
+                for (int j = 0; j < cnt && slot < MAXNB; ++j, ++slot) {
+                    const int sp = hi - 1 - j;
+                    row[slot] = sp; srow[slot] = (uint16_t)i;
+                    if (MARK) evad_mark_edge_packed(node_vox[sp], my_vox, my_slot, bitmap, flags);
+                }
+            } else {
+                const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+                const int p = plane_base + xn + W * yn;
+                const int st = (int)start[p], en = (int)start[p + 1], lo0 = max(st, en - Q);
+                for (int s = en - 1; s >= lo0 && slot < MAXNB; --s) {
+                    const int2 c = ev2[s];
+                    if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) {
+                        row[slot] = s; srow[slot] = (uint16_t)i;
+                        if (MARK) evad_mark_edge_packed(node_vox[s], my_vox, my_slot, bitmap, flags);
+                        ++slot;
+                    }
+                }
+            }
+        }
+        filled = min(MAXNB, filled + total);
+    }
+    if (lane == 0) deg[ev] = filled;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Thread-per-event edge search without data-dependent inner loops.
+// PMC counters say every variant above spends ~200-300 VALU+SALU wave-instructions PER EVENT: the
+// thread-per-event walk because a wave executes, at each spiral step, the longest FIFO walk of its 64
+// lanes (divergence factor ~12), the wave- and row-parallel forms because most of their lanes sit on empty
+// pixels.  Here all 64 lanes of a wave stay converged: 8 spiral steps are processed together, the valid
+// source range [lo, hi) of each of their pixels is found by FIXED-trip binary searches (trip count =
+// bits of the longest pixel segment of the batch, measured by eventad_sort_events, capped by the FIFO
+// depth) whose loads are independent across the 8 steps, and only the final append of <= 15 sources into
+// the lane's LDS-staged ELL row is a (short) per-lane loop.  Requires timestamps non-decreasing in id
+// (contiguous valid ranges); otherwise the exact linear scan of the reference runs instead.
+#define BF_GROUP 8
+template <bool MARK>
+__global__ __launch_bounds__(256) void k_build_ell_bf(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+                                                      const unsigned* __restrict__ start, const unsigned* flags_in, int N, int W,
+                                                      int H, int steps, int Q, int dt_max, int* __restrict__ ell_src,
+                                                      uint16_t* __restrict__ ell_step, int* __restrict__ deg,
+                                                      const int* __restrict__ node_slot, const int* __restrict__ node_vox,
+                                                      unsigned* __restrict__ bitmap, unsigned* flags) {
+    constexpr int MAXNB = 16;
+    __shared__ int s_row[256][MAXNB + 1];                    // +1: conflict-free per-lane rows
+    __shared__ unsigned short s_stp[256][MAXNB + 2];
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x * 256 + tid;
+    const bool active = r < N;
+    const bool monotone = !(flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE);
+    const int lmax = min((int)flags_in[3], Q);
+    const int iters = 32 - __clz(max(lmax, 1));              // ceil(log2(lmax + 1))
+    int me = 0, ts = 0, x = 0, y = 0, plane_base = 0;
+    if (active) {
+        const int k = key_s[r];
+        const int2 mine = ev2[r];
+        me = mine.x; ts = mine.y; x = k % W; y = (k / W) % H; plane_base = k - x - W * y;
+    }
+#pragma unroll
+    for (int e = 0; e < MAXNB; ++e) { s_row[tid][e] = 0; s_stp[tid][e] = 0; }
+    s_row[tid][0] = r;
+    int nn = active ? 1 : MAXNB;                             // inactive lanes count as "full"
+    for (int i0 = 0; i0 < steps; i0 += BF_GROUP) {
+        if (__all(nn >= MAXNB)) break;                       // every lane of the wave is done
+        int st[BF_GROUP], en[BF_GROUP], a[BF_GROUP], b[BF_GROUP];
+#pragma unroll
+        for (int u = 0; u < BF_GROUP; ++u) {
+            st[u] = 0; en[u] = 0;
+            const int i = i0 + u;
+            if (i < steps && nn < MAXNB) {
+                const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+                if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
+                    const int p = plane_base + xn + W * yn;
+                    st[u] = (int)start[p]; en[u] = (int)start[p + 1];
+                }
+            }
+        }
+        if (monotone) {
+            // two independent searches per pixel, in lockstep: a -> hi = first position with id >= mine,
+            // lo -> first position with ts - t <= dt_max (newer events have ts - t <= 0, so the predicate is
+            // monotone over the whole segment); valid sources are [lo, hi)
+            int lo[BF_GROUP], lb[BF_GROUP];
+#pragma unroll
+            for (int u = 0; u < BF_GROUP; ++u) { st[u] = max(st[u], en[u] - Q); a[u] = st[u]; b[u] = en[u]; lo[u] = st[u]; lb[u] = en[u]; }
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < BF_GROUP; ++u) {
+                    const int m = (a[u] + b[u]) >> 1, m2 = (lo[u] + lb[u]) >> 1;
+                    if (a[u] < b[u]) { if (ev2[m].x < me) a[u] = m + 1; else b[u] = m; }
+                    if (lo[u] < lb[u]) { if (ts - ev2[m2].y > dt_max) lo[u] = m2 + 1; else lb[u] = m2; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BF_GROUP; ++u) {             // append hi-1 .. lo, newest first
+                const int cnt = a[u] - lo[u];
+                for (int j = 0; j < cnt && nn < MAXNB; ++j, ++nn) { s_row[tid][nn] = a[u] - 1 - j; s_stp[tid][nn] = (unsigned short)(i0 + u); }
+            }
+        } else {                                             // exact reference scan (ev_graph.cu:51-76)
+#pragma unroll
+            for (int u = 0; u < BF_GROUP; ++u) {
+                const int lo0 = max(st[u], en[u] - Q);
+                for (int sp = en[u] - 1; sp >= lo0 && nn < MAXNB; --sp) {
+                    const int2 c = ev2[sp];
+                    if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) { s_row[tid][nn] = sp; s_stp[tid][nn] = (unsigned short)(i0 + u); ++nn; }
+                }
+            }
+        }
+    }
+    if (!active) return;
+    int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rp[q] = make_int4(s_row[tid][4 * q], s_row[tid][4 * q + 1], s_row[tid][4 * q + 2], s_row[tid][4 * q + 3]);
+    uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const unsigned short* c = &s_stp[tid][8 * q];
+        sp4[q] = make_uint4(c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16, c[6] | c[7] << 16);
+    }
+    deg[r] = nn;
+    if (MARK) {
+        const int my_slot = node_slot[r], my_vox = node_vox[r];
+        int vs[MAXNB];
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[s_row[tid][e]] : my_vox;
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Same converged-lane search, with the pixel table and the FIFO entries of a row strip (+ halo) staged in
+// LDS.  The global-memory form above is bound by the CU's vector-memory issue rate (~560 wave-level loads
+// per 64 events, each occupying the texture-address path for ~16 cycles); here one workgroup owns R pixel
+// rows of one clip, stages start[] of rows [y0-rad, y0+R+rad) and the (contiguous, pixel-sorted) events of
+// those rows once with coalesced loads, and the searches read LDS.  Events that do not fit the staged
+// window (CAP) are read from global memory, so dense strips stay correct.
+template <bool MARK>
+__global__ __launch_bounds__(256) void k_build_ell_tile(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+                                                        const unsigned* __restrict__ start, const unsigned* flags_in, int W, int H,
+                                                        int R, int rad, int steps, int Q, int dt_max, int TBL, int CAP,
+                                                        int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
+                                                        int* __restrict__ deg, const int* __restrict__ node_slot,
+                                                        const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
+                                                        unsigned* flags) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+    constexpr int MAXNB = 16, RS = MAXNB + 1, SS = MAXNB + 2;
+    int* s_start = s_dyn;                                    // [TBL]
+    int2* s_ev = (int2*)(s_dyn + TBL);                       // [CAP]
+    int* s_row = (int*)(s_ev + CAP);                         // [256][17]
+    unsigned short* s_stp = (unsigned short*)(s_row + 256 * RS);   // [256][18]
+    const int tid = threadIdx.x;
+    const int strips = (H + R - 1) / R;
+    const int b = blockIdx.x / strips, y0 = (blockIdx.x % strips) * R;
+    const int ylo = max(y0 - rad, 0), yhi = min(y0 + R + rad, H);
+    const int plane_base = b * W * H, p_lo = plane_base + ylo * W, nt = (yhi - ylo) * W + 1;
+    for (int i = tid; i < nt; i += 256) s_start[i] = (int)start[p_lo + i];
+    __syncthreads();
+    const int ev_lo = s_start[0], nstage = min(s_start[nt - 1] - ev_lo, CAP);
+    for (int i = tid; i < nstage; i += 256) s_ev[i] = ev2[ev_lo + i];
+    __syncthreads();
+    const bool monotone = !(flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE);
+    const int lmax = min((int)flags_in[3], Q);
+    const int iters = 32 - __clz(max(lmax, 1));
+    const int my_lo = s_start[(y0 - ylo) * W], my_hi = s_start[(min(y0 + R, H) - ylo) * W];
+    auto fetch = [&](int m) -> int2 { const int o = m - ev_lo; return o < CAP ? s_ev[o] : ev2[m]; };
+    int* row = s_row + tid * RS;
+    unsigned short* stp = s_stp + tid * SS;
+    for (int base = my_lo; base < my_hi; base += 256) {
+        const int r = base + tid;
+        const bool active = r < my_hi;
+        int me = 0, ts = 0, x = 0, y = 0;
+        if (active) {
+            const int k = key_s[r];
+            const int2 mine = fetch(r);
+            me = mine.x; ts = mine.y; x = k % W; y = (k / W) % H;
+        }
+#pragma unroll
+        for (int e = 0; e < MAXNB; ++e) { row[e] = 0; stp[e] = 0; }
+        row[0] = r;
+        int nn = active ? 1 : MAXNB;
+        for (int i0 = 0; i0 < steps; i0 += BF_GROUP) {
+            if (__all(nn >= MAXNB)) break;
+            int st[BF_GROUP], en[BF_GROUP], a[BF_GROUP], b2[BF_GROUP];
+#pragma unroll
+            for (int u = 0; u < BF_GROUP; ++u) {
+                st[u] = 0; en[u] = 0;
+                const int i = i0 + u;
+                if (i < steps && nn < MAXNB) {
+                    const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+                    if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
+                        const int idx = (yn - ylo) * W + xn;
+                        st[u] = s_start[idx]; en[u] = s_start[idx + 1];
+                    }
+                }
+            }
+            if (monotone) {
+                int lo[BF_GROUP], lb[BF_GROUP];
+#pragma unroll
+                for (int u = 0; u < BF_GROUP; ++u) { st[u] = max(st[u], en[u] - Q); a[u] = st[u]; b2[u] = en[u]; lo[u] = st[u]; lb[u] = en[u]; }
+                for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                    for (int u = 0; u < BF_GROUP; ++u) {
+                        const int m = (a[u] + b2[u]) >> 1, m2 = (lo[u] + lb[u]) >> 1;
+                        if (a[u] < b2[u]) { if (fetch(m).x < me) a[u] = m + 1; else b2[u] = m; }
+                        if (lo[u] < lb[u]) { if (ts - fetch(m2).y > dt_max) lo[u] = m2 + 1; else lb[u] = m2; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BF_GROUP; ++u) {
+                    const int cnt = a[u] - lo[u];
+                    for (int j = 0; j < cnt && nn < MAXNB; ++j, ++nn) { row[nn] = a[u] - 1 - j; stp[nn] = (unsigned short)(i0 + u); }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < BF_GROUP; ++u) {
+                    const int lo0 = max(st[u], en[u] - Q);
+                    for (int sp = en[u] - 1; sp >= lo0 && nn < MAXNB; --sp) {
+                        const int2 c = fetch(sp);
+                        if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) { row[nn] = sp; stp[nn] = (unsigned short)(i0 + u); ++nn; }
+                    }
+                }
+            }
+        }
+        if (active) {
+            int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rp[q] = make_int4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+            uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned short* c = stp + 8 * q;
+                sp4[q] = make_uint4(c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16, c[6] | c[7] << 16);
+            }
+            deg[r] = nn;
+            if (MARK) {
+                const int my_slot = node_slot[r], my_vox = node_vox[r];
+                int vs[MAXNB];
+#pragma unroll
+                for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[row[e]] : my_vox;
+#pragma unroll
+                for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
+            }
+        }
+    }
+}
+
+// LDS plan of k_build_ell_tile: rows per workgroup, table length, staged-event capacity; false = does not fit
+static bool tile_plan(int B, int W, int H, int rad, int* R, int* TBL, int* CAP, size_t* lds) {
+    const int rows_bytes = 256 * (17 * 4 + 18 * 2);
+    int r = (int)(((long long)B * H) / 512);
+    r = r < 1 ? 1 : (r > 8 ? 8 : r);
+    for (; r >= 1; r >>= 1) {
+        int tbl = (((r + 2 * rad) * W + 1) + 3) & ~3;
+        long long left = 64 * 1024 - rows_bytes - (long long)tbl * 4;
+        if (left >= 512 * 8) { *R = r; *TBL = tbl; *CAP = (int)(left / 8); *lds = (size_t)tbl * 4 + (size_t)*CAP * 8 + rows_bytes; return true; }
+    }
+    return false;
+}
+
 extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                                  const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
@@ -818,7 +1148,26 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
     int steps;
     if (ensure_spiral(radius_px, st, &steps)) return -2;
     if (steps > 65535) return EVAD_ERR_ARG;
-    if (max_num_neighbors == 16 && ev2 && strip_width == -2 && (radius_px == 1 || radius_px == 3 || radius_px == 7 || radius_px == 13)) {
+    int tR = 0, tTBL = 0, tCAP = 0; size_t tlds = 0;
+    if (max_num_neighbors == 16 && ev2 && strip_width == -5 && radius_px <= SPIRAL_MAX_R && tile_plan(B, W, H, radius_px, &tR, &tTBL, &tCAP, &tlds)) {
+        dim3 grid((unsigned)(B * ((H + tR - 1) / tR)));
+        if (bitmap) hipLaunchKernelGGL(k_build_ell_tile<true>, grid, dim3(256), tlds, st, (const int2*)ev2, key_s, pix_start, counters, W, H, tR,
+                                       radius_px, steps, queue_size, delta_t_us, tTBL, tCAP, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        else        hipLaunchKernelGGL(k_build_ell_tile<false>, grid, dim3(256), tlds, st, (const int2*)ev2, key_s, pix_start, counters, W, H, tR,
+                                       radius_px, steps, queue_size, delta_t_us, tTBL, tCAP, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+    } else if (max_num_neighbors == 16 && ev2 && (strip_width == -4 || strip_width == -5) && radius_px <= SPIRAL_MAX_R) {
+        dim3 grid(evad_blocks(N, 256));
+        if (bitmap) hipLaunchKernelGGL(k_build_ell_bf<true>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
+                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        else        hipLaunchKernelGGL(k_build_ell_bf<false>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
+                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+    } else if (max_num_neighbors == 16 && ev2 && strip_width == -3 && radius_px <= SPIRAL_MAX_R) {
+        dim3 grid(evad_blocks(N, 4));
+        if (bitmap) hipLaunchKernelGGL(k_build_ell_wave<true>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
+                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        else        hipLaunchKernelGGL(k_build_ell_wave<false>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
+                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+    } else if (max_num_neighbors == 16 && ev2 && strip_width == -2 && (radius_px == 1 || radius_px == 3 || radius_px == 7 || radius_px == 13)) {
         const int2* e2 = (const int2*)ev2;
         if (radius_px == 1)       launch_rows<1, 4>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
         else if (radius_px == 3)  launch_rows<3, 8>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);

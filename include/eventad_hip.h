@@ -55,7 +55,8 @@ int eventad_spiral_offsets(int radius, int16_t* dxdy);
  *   out: key/tq/bev i32[N] (event order: pixel key, t in us, clip), pix_start u32[B*H*W+1],
  *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], ev2 i32[N,2] = {id, t} pairs (nullable), posn_s f32[N,3], x0s f32[N,20]
  *   ws : pix_count u32[B*H*W+1], scan_tmp u32[B*H*W/2048+2], sid_tmp i32[N], long_list i32[B*H*W],
- *        counters u32[4] ([0] = EVENTAD_FLAG_* bits, caller zeroes it; [1] internal; [2] = length of ovf_list)
+ *        counters u32[4] ([0] = EVENTAD_FLAG_* bits, caller zeroes it; [1] internal; [2] = length of ovf_list;
+ *        [3] = longest pixel segment of the batch)
  *   pool1 prep (node_slot nullable = skip): node_slot i32[N] = voxel slot of each sorted event computed from its
  *        float position as grid_cluster does (pooling.py:55-56); px_to_cx i32[W] / py_to_cy i32[H] = voxel of a
  *        pixel; node_vox i32[N] = the slot decomposed as cx | cy<<8 | plane<<16; events whose slot differs from their pixel's (t == time_window, off-grid positions) -> ovf_list */
@@ -70,7 +71,9 @@ int eventad_sort_events(const float* pos, const int64_t* batch, const float* pol
  * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
  * the source-voxel bit in the destination voxel's pool1 neighbour bitmap u32[S,3] (= eventad_pool_edges_mark_ell).
  * strip_width (needs ev2): > 0 LDS-staged search, one wave per strip of that many pixels of a sensor row;
- * < 0 thread per event with the row kept in registers; 0 batched prefetch.  All variants give identical rows. */
+ * 0 batched prefetch; -1 thread per event, row in registers (default); -2 row-parallel; -3 wave per event with
+ * binary-searched ranges; -4 converged lanes with fixed-trip binary searches; -5 the same over LDS-staged row
+ * strips.  All variants give identical rows. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                       int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step, int32_t* deg,
