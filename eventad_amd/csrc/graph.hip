@@ -264,7 +264,7 @@ __global__ void k_scatter_events(const int* __restrict__ key, const unsigned* __
     // longest pixel segment of the batch (bounds the binary searches of k_build_ell_bf): one atomic per wave
     unsigned m = c;
     for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(lmax, m);
+    if ((threadIdx.x & 63) == 0 && m > *(volatile unsigned*)lmax) atomicMax(lmax, m);   // a same-address atomic per wave costs 60 us
 }
 
 // Order every pixel segment by event id (rank placement; ids are unique).  Short segments are

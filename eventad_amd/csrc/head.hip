@@ -324,6 +324,170 @@ extern "C" int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int3
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused recurrent step: GRU cell + SpatialAttention of one clip in ONE workgroup per problem (1024 threads,
+// thread = (track row k = tid>>5, lane c = tid&31) owning hidden columns c, c+32, ...).  The head is a chain
+// of B dependent clip steps over 32 rows each, i.e. pure launch latency: fusing the element-wise cell with
+// the row-reduction attention that consumes it (and, on the way back, the attention backward with the cell
+// backward) halves the number of dependent launches; eventad_amd/head_native.py additionally runs GRU layer 1
+// one clip behind layer 0 so both layers share each launch.
+struct StepProb { const float* gi; const float* gh; const float* hprev; float* gates; float* hn; const float* mask;
+                  float* xdrop; const float* w; float* alpha; float* snext; const int* valid; int H; };
+struct StepGroup { StepProb p[3]; int n; };
+
+template <int CH>
+__device__ __forceinline__ void step_fwd_body(const StepProb& P) {
+    constexpr int H = CH * 32;
+    __shared__ float s_s[NT];
+    __shared__ int s_v[NT];
+    const int tid = threadIdx.x, k = tid >> 5, c = tid & 31;
+    if (tid < NT) s_v[tid] = P.valid[tid];
+    const float* a = P.gi + (size_t)k * 3 * H; const float* b = P.gh + (size_t)k * 3 * H;
+    float* gt = P.gates + (size_t)k * 3 * H;
+    float hn[CH], hp[CH];
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = c + 32 * i;
+        const float r = sigmoidf_(a[j] + b[j]);
+        const float z = sigmoidf_(a[H + j] + b[H + j]);
+        const float n = tanhf_(a[2 * H + j] + r * b[2 * H + j]);
+        hp[i] = P.hprev[(size_t)k * H + j];
+        hn[i] = (1.f - z) * n + z * hp[i];
+        gt[j] = r; gt[H + j] = z; gt[2 * H + j] = n;
+        P.hn[(size_t)k * H + j] = hn[i];
+        if (P.xdrop) P.xdrop[(size_t)k * H + j] = P.mask ? hn[i] * P.mask[(size_t)k * H + j] : hn[i];
+        part += tanhf_(hn[i]) * P.w[j];
+    }
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (c == 0) s_s[k] = part;
+    __syncthreads();
+    float m = -3.4e38f;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) if (s_v[q]) m = fmaxf(m, s_s[q]);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) if (s_v[q]) sum += expf(s_s[q] - m);
+    const bool v = s_v[k] != 0;
+    const float al = v ? expf(s_s[k] - m) / sum : 0.f;
+    if (c == 0) P.alpha[k] = al;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) P.snext[(size_t)k * H + c + 32 * i] = v ? hn[i] * al : hp[i];
+}
+
+__global__ __launch_bounds__(1024) void k_step_fwd(StepGroup g) {
+    const StepProb& P = g.p[blockIdx.x];
+    if (P.H == 256) step_fwd_body<8>(P); else step_fwd_body<1>(P);
+}
+
+/* desc: HOST array, 12 int64 per problem: [0] gi [1] gh [2] hprev (= the attention's kept state) [3] gates out
+ * [4] hn out [5] dropout mask (0 = none) [6] xdrop out (0 = none) [7] attention w [8] alpha out [9] snext out
+ * [10] valid i32[32] [11] H (256 or 32). */
+extern "C" int eventad_gru_att_fwd_group(int n, const int64_t* d, void* stream) {
+    if (n < 1 || n > 3 || !d) return EVAD_ERR_ARG;
+    StepGroup g; g.n = n;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* q = d + 12 * i; StepProb& P = g.p[i];
+        P.gi = (const float*)q[0]; P.gh = (const float*)q[1]; P.hprev = (const float*)q[2]; P.gates = (float*)q[3];
+        P.hn = (float*)q[4]; P.mask = (const float*)q[5]; P.xdrop = (float*)q[6]; P.w = (const float*)q[7];
+        P.alpha = (float*)q[8]; P.snext = (float*)q[9]; P.valid = (const int*)q[10]; P.H = (int)q[11];
+        if (!P.gi || !P.gh || !P.hprev || !P.gates || !P.hn || !P.w || !P.alpha || !P.snext || !P.valid || (P.H != 256 && P.H != 32))
+            return EVAD_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_step_fwd, dim3(n), dim3(1024), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}
+
+struct StepBwdProb { const float* hn; const float* w; const float* alpha; const float* dsnext; const float* dhn_out;
+                     const int* valid; float* dw; const float* dx_extra; const float* mask; const float* gates;
+                     const float* gh; const float* hprev; float* dgi; float* dgh; float* dsprev; int H; };
+struct StepBwdGroup { StepBwdProb p[3]; int n; };
+
+template <int CH>
+__device__ __forceinline__ void step_bwd_body(const StepBwdProb& P) {
+    constexpr int H = CH * 32;
+    __shared__ float s_da[NT], s_al[NT], s_c[NT][H + 1];
+    __shared__ int s_v[NT];
+    const int tid = threadIdx.x, k = tid >> 5, c = tid & 31;
+    if (tid < NT) { s_v[tid] = P.valid[tid]; s_al[tid] = P.alpha[tid]; }
+    float hn[CH], gs[CH];
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const size_t t = (size_t)k * H + c + 32 * i;
+        hn[i] = P.hn[t]; gs[i] = P.dsnext[t];
+        part += gs[i] * hn[i];
+    }
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    __syncthreads();
+    if (c == 0) s_da[k] = s_v[k] ? part : 0.f;
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) if (s_v[q]) dot += s_al[q] * s_da[q];
+    const bool v = s_v[k] != 0;
+    const float al = s_al[k], ds = v ? al * (s_da[k] - dot) : 0.f;
+    const float* gt = P.gates + (size_t)k * 3 * H;
+    float* a = P.dgi + (size_t)k * 3 * H; float* cg = P.dgh + (size_t)k * 3 * H;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = c + 32 * i;
+        const size_t t = (size_t)k * H + j;
+        const float th = tanhf_(hn[i]);
+        float dh = 0.f, dspass = gs[i];                      // state kept: the gradient passes through
+        if (v) {
+            dh = gs[i] * al + ds * P.w[j] * (1.f - th * th);
+            if (P.dhn_out) dh += P.dhn_out[t];
+            dspass = 0.f;
+        }
+        s_c[k][j] = ds * th;
+        // GRU cell backward (see k_gru_cell_bwd)
+        if (P.dx_extra) dh += P.mask ? P.dx_extra[t] * P.mask[t] : P.dx_extra[t];
+        const float r = gt[j], z = gt[H + j], n = gt[2 * H + j];
+        const float ghn = P.gh[(size_t)k * 3 * H + 2 * H + j];
+        const float h = P.hprev[t];
+        const float dn = dh * (1.f - z), dz = dh * (h - n);
+        const float dan = dn * (1.f - n * n), daz = dz * z * (1.f - z), dar = dan * ghn * r * (1.f - r);
+        a[j] = dar; a[H + j] = daz; a[2 * H + j] = dan;
+        cg[j] = dar; cg[H + j] = daz; cg[2 * H + j] = dan * r;
+        P.dsprev[t] = dspass + dh * z;
+    }
+    __syncthreads();
+    if (tid < H) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc += s_c[q][tid];
+        P.dw[tid] += acc;                                   // every problem of a launch owns its own dw accumulator
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_step_bwd(StepBwdGroup g) {
+    const StepBwdProb& P = g.p[blockIdx.x];
+    if (P.H == 256) step_bwd_body<8>(P); else step_bwd_body<1>(P);
+}
+
+/* desc: HOST array, 16 int64 per problem: [0] hn [1] attention w [2] alpha [3] dsnext [4] dhn_out (0 = none)
+ * [5] valid [6] dw accumulator [7] dx_extra (0 = none) [8] mask (0 = none) [9] gates [10] gh [11] hprev
+ * [12] dgi out [13] dgh out [14] dsprev out [15] H. */
+extern "C" int eventad_gru_att_bwd_group(int n, const int64_t* d, void* stream) {
+    if (n < 1 || n > 3 || !d) return EVAD_ERR_ARG;
+    StepBwdGroup g; g.n = n;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* q = d + 16 * i; StepBwdProb& P = g.p[i];
+        P.hn = (const float*)q[0]; P.w = (const float*)q[1]; P.alpha = (const float*)q[2]; P.dsnext = (const float*)q[3];
+        P.dhn_out = (const float*)q[4]; P.valid = (const int*)q[5]; P.dw = (float*)q[6]; P.dx_extra = (const float*)q[7];
+        P.mask = (const float*)q[8]; P.gates = (const float*)q[9]; P.gh = (const float*)q[10]; P.hprev = (const float*)q[11];
+        P.dgi = (float*)q[12]; P.dgh = (float*)q[13]; P.dsprev = (float*)q[14]; P.H = (int)q[15];
+        if (!P.hn || !P.w || !P.alpha || !P.dsnext || !P.valid || !P.dw || !P.gates || !P.gh || !P.hprev || !P.dgi || !P.dgh ||
+            !P.dsprev || (P.H != 256 && P.H != 32))
+            return EVAD_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_step_bwd, dim3(n), dim3(1024), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Output layer + cross-entropy (Fuse_GRUNet.fusion[3], EventAD.py:27,280-281): one wave per row.
 // F1r = ReLU(fusion.0(...)) [R,256]; D2 = dropout mask (nullable).  Writes logits, d(loss)/d(logits)
 // (masked by validity) and the per-row loss; k_loss_sum adds the rows in (clip, track) order, which

@@ -157,23 +157,29 @@ class NativeHead:
         self._gg((0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, P[ev + "bias_ih_l0"]),
                  (0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, P[co + "bias_ih_l0"]))
         w["S0"][:NT].zero_(); w["S1"][:NT].zero_(); w["SC"][:NT].zero_()
-        for b in range(B):                                     # the clip-to-clip hidden-state chain (EventAD.py:211-323)
-            r0, r1 = b * NT, (b + 1) * NT
-            vb = w["valid"][r0:r1]
-            self._gg((0, 1, w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, P[ev + "bias_hh_l0"]),
-                     (0, 1, w["S1"][r0:r1], 256, P[ev + "weight_hh_l1"], 256, w["GH1"][r0:r1], 768, NT, 768, 256, P[ev + "bias_hh_l1"]),
-                     (0, 1, w["SC"][r0:r1], 32, P[co + "weight_hh_l0"], 32, w["GHC"][r0:r1], 96, NT, 96, 32, P[co + "bias_hh_l0"]))
-            d1 = self.D1[r0:r1] if train else None
-            self._desc("eventad_gru_cell_fwd_group", 12,
-                       [[w["GI0"][r0:r1], w["GH0"][r0:r1], w["S0"][r0:r1], w["G0"][r0:r1], w["H0n"][r0:r1], d1, w["X1"][r0:r1], 256],
-                        [w["GIC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["GC"][r0:r1], w["HCn"][r0:r1], None, None, 32]])
-            self._gg((0, 1, w["X1"][r0:r1], 256, P[ev + "weight_ih_l1"], 256, w["GI1"][r0:r1], 768, NT, 768, 256, P[ev + "bias_ih_l1"]))
-            self._desc("eventad_gru_cell_fwd_group", 12,
-                       [[w["GI1"][r0:r1], w["GH1"][r0:r1], w["S1"][r0:r1], w["G1"][r0:r1], w["H1n"][r0:r1], None, None, 256]])
-            self._att("eventad_att_fwd_group", vb,
-                      dict(Hn=w["H0n"][r0:r1], Sprev=w["S0"][r0:r1], w=watt, alpha=w["AL0"][r0:r1], Snext=w["S0"][r1:r1 + NT], H=256),
-                      dict(Hn=w["H1n"][r0:r1], Sprev=w["S1"][r0:r1], w=watt, alpha=w["AL1"][r0:r1], Snext=w["S1"][r1:r1 + NT], H=256),
-                      dict(Hn=w["HCn"][r0:r1], Sprev=w["SC"][r0:r1], w=wattc, alpha=w["ALC"][r0:r1], Snext=w["SC"][r1:r1 + NT], H=32))
+        # The clip-to-clip hidden-state chain (EventAD.py:211-323) as a wavefront: stage b runs GRU layer 0 and the
+        # coordinate GRU on clip b and GRU layer 1 on clip b-1 (its input, the dropout'd layer-0 output of clip
+        # b-1, and its state, the layer-1 attention of clip b-2, are both a stage old), so one stage is two
+        # dependent launches -- a grouped GEMM and a fused cell+attention -- instead of five.
+        for b in range(B + 1):
+            gemms, steps = [], []
+            if b < B:
+                r0, r1 = b * NT, (b + 1) * NT
+                gemms += [(0, 1, w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, P[ev + "bias_hh_l0"]),
+                          (0, 1, w["SC"][r0:r1], 32, P[co + "weight_hh_l0"], 32, w["GHC"][r0:r1], 96, NT, 96, 32, P[co + "bias_hh_l0"])]
+                vb = w["valid"][r0:r1]
+                steps += [[w["GI0"][r0:r1], w["GH0"][r0:r1], w["S0"][r0:r1], w["G0"][r0:r1], w["H0n"][r0:r1],
+                           self.D1[r0:r1] if train else None, w["X1"][r0:r1], watt, w["AL0"][r0:r1], w["S0"][r1:r1 + NT], vb, 256],
+                          [w["GIC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["GC"][r0:r1], w["HCn"][r0:r1],
+                           None, None, wattc, w["ALC"][r0:r1], w["SC"][r1:r1 + NT], vb, 32]]
+            if b >= 1:
+                q0, q1 = (b - 1) * NT, b * NT
+                gemms += [(0, 1, w["S1"][q0:q1], 256, P[ev + "weight_hh_l1"], 256, w["GH1"][q0:q1], 768, NT, 768, 256, P[ev + "bias_hh_l1"]),
+                          (0, 1, w["X1"][q0:q1], 256, P[ev + "weight_ih_l1"], 256, w["GI1"][q0:q1], 768, NT, 768, 256, P[ev + "bias_ih_l1"])]
+                steps += [[w["GI1"][q0:q1], w["GH1"][q0:q1], w["S1"][q0:q1], w["G1"][q0:q1], w["H1n"][q0:q1],
+                           None, None, watt, w["AL1"][q0:q1], w["S1"][q1:q1 + NT], w["valid"][q0:q1], 256]]
+            self._gg(*gemms)
+            self._desc("eventad_gru_att_fwd_group", 12, steps)
         # fusion MLP on all rows at once (Fuse_GRUNet.forward, EventAD.py:30-59)
         self._gg((0, 1, w["H1n"], 256, P[fu + "event_proj.weight"], 256, w["ZCAT"], 512, R, 256, 256, P[fu + "event_proj.bias"]),
                  (0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, P[fu + "coord_proj.bias"]))
@@ -209,32 +215,33 @@ class NativeHead:
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
         gattc = G["soft_attention_cor.weight"]
         w["dwatt0"].zero_(); w["dwatt1"].zero_()
-        for b in range(B - 1, -1, -1):
-            r0, r1 = b * NT, (b + 1) * NT
-            vb = w["valid"][r0:r1]
-            self._att("eventad_att_bwd_group", vb,
-                      dict(Hn=w["H1n"][r0:r1], w=watt, alpha=w["AL1"][r0:r1], dSnext=d1, dHn_out=w["dH1o"][r0:r1], dHn=w["dHn1"],
-                           dSpass=w["dSp1"], dw=w["dwatt1"], H=256),
-                      dict(Hn=w["HCn"][r0:r1], w=wattc, alpha=w["ALC"][r0:r1], dSnext=dc, dHn_out=w["dHCo"][r0:r1], dHn=w["dHnC"],
-                           dSpass=w["dSpC"], dw=gattc, H=32),
-                      dict(Hn=w["H0n"][r0:r1], w=watt, alpha=w["AL0"][r0:r1], dSnext=d0, dHn_out=None, dHn=w["dHn0"],
-                           dSpass=w["dSp0"], dw=w["dwatt0"], H=256))
-            self._desc("eventad_gru_cell_bwd_group", 12,
-                       [[w["dHn1"], None, None, w["G1"][r0:r1], w["GH1"][r0:r1], w["S1"][r0:r1], w["dSp1"], w["dGI1"][r0:r1],
-                         w["dGH1"][r0:r1], n1, 256],
-                        [w["dHnC"], None, None, w["GC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["dSpC"], w["dGIC"][r0:r1],
-                         w["dGHC"][r0:r1], nc, 32]])
-            self._gg((0, 0, w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, None, 0, 1),
-                     (0, 0, w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, None, 0, 1),
-                     (0, 0, w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768))
-            dm = self.D1[r0:r1] if train else None
-            self._desc("eventad_gru_cell_bwd_group", 12,
-                       [[w["dHn0"], w["dX1"], dm, w["G0"][r0:r1], w["GH0"][r0:r1], w["S0"][r0:r1], w["dSp0"], w["dGI0"][r0:r1],
-                         w["dGH0"][r0:r1], n0, 256]])
-            self._gg((0, 0, w["dGH0"][r0:r1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, None, 0, 1))
-            d0, n0 = n0, d0
-            d1, n1 = n1, d1
-            dc, nc = nc, dc
+        # reverse wavefront: stage b runs layer 1 + the coordinate GRU on clip b and layer 0 on clip b+1 (whose
+        # dX1 and dS0 come out of the previous stage's GEMMs): fused attention+cell backward, then one grouped GEMM
+        for b in range(B - 1, -2, -1):
+            steps, gemms = [], []
+            if b >= 0:
+                r0, r1 = b * NT, (b + 1) * NT
+                vb = w["valid"][r0:r1]
+                steps += [[w["H1n"][r0:r1], watt, w["AL1"][r0:r1], d1, w["dH1o"][r0:r1], vb, w["dwatt1"], None, None,
+                           w["G1"][r0:r1], w["GH1"][r0:r1], w["S1"][r0:r1], w["dGI1"][r0:r1], w["dGH1"][r0:r1], n1, 256],
+                          [w["HCn"][r0:r1], wattc, w["ALC"][r0:r1], dc, w["dHCo"][r0:r1], vb, gattc, None, None,
+                           w["GC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["dGIC"][r0:r1], w["dGHC"][r0:r1], nc, 32]]
+                gemms += [(0, 0, w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, None, 0, 1),
+                          (0, 0, w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, None, 0, 1),
+                          (0, 0, w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768)]
+            if b + 1 < B:
+                q0, q1 = (b + 1) * NT, (b + 2) * NT
+                steps += [[w["H0n"][q0:q1], watt, w["AL0"][q0:q1], d0, None, w["valid"][q0:q1], w["dwatt0"], w["dX1"],
+                           self.D1[q0:q1] if train else None, w["G0"][q0:q1], w["GH0"][q0:q1], w["S0"][q0:q1],
+                           w["dGI0"][q0:q1], w["dGH0"][q0:q1], n0, 256]]
+                gemms += [(0, 0, w["dGH0"][q0:q1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, None, 0, 1)]
+            self._desc("eventad_gru_att_bwd_group", 16, steps)
+            self._gg(*gemms)
+            if b >= 0:
+                d1, n1 = n1, d1
+                dc, nc = nc, dc
+            if b + 1 < B:
+                d0, n0 = n0, d0
         torch.add(w["dwatt0"], w["dwatt1"], out=G["soft_attention.weight"].view(-1))
         # weight gradients of the recurrent layers, batched over all clips: ONE launch (+ one reduce)
         self._gg((1, 0, w["dGI0"], 768, w["X"], 64, G[ev + "weight_ih_l0"], 64, 768, 64, R),

@@ -123,6 +123,8 @@ class TrainStep:
                 body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if getattr(self, "graph", None) is not None:          # keep an earlier capture (and its private pool) alive:
+            self._retired = getattr(self, "_retired", []) + [self.graph]   # buffers first allocated under it stay mapped
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread polls events while the capture is open
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):

@@ -172,6 +172,16 @@ int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* m
  * valid i32[32] = the clip's track mask (device). */
 int eventad_att_fwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
 int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
+/* Fused recurrent step of the head (Fuse_GRUNet / SpatialAttention, models/EventAD.py:62-138): GRU cell + attention
+ * of one clip, one 1024-thread workgroup per problem, up to 3 problems per launch.
+ * fwd desc = HOST array, 12 int64 per problem: [0] gi [1] gh [2] hprev (= the state the attention keeps for invalid
+ * tracks) [3] gates out [4] hn out [5] dropout mask(0=none) [6] xdrop out(0=none) [7] attention w [8] alpha out
+ * [9] snext out [10] valid i32[32] [11] H (256|32).
+ * bwd desc = 16 int64 per problem: [0] hn [1] attention w [2] alpha [3] dsnext [4] dhn_out(0=none) [5] valid
+ * [6] dw accumulator [7] dx_extra(0=none) [8] mask(0=none) [9] gates [10] gh [11] hprev [12] dgi out [13] dgh out
+ * [14] dsprev out [15] H. */
+int eventad_gru_att_fwd_group(int n_prob, const int64_t* desc, void* stream);
+int eventad_gru_att_bwd_group(int n_prob, const int64_t* desc, void* stream);
 /* Up to 8 independent small GEMMs per launch (one workgroup per 32x32 tile, its 4 waves split K in 64-deep
  * chunks and are summed in wave order = deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B
  * [2] part scratch f32[ceil(K/256)][M][N] (only when K > 256) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K
