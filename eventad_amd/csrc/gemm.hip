@@ -272,7 +272,7 @@ extern "C" int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int
 // =============================================================================================
 #define TG_MAXP 8
 struct TProb {
-    const float* A; const float* B; float* C; const float* bias; float* part;
+    const float* A; const float* B; float* C; const float* bias; float* part; int* cnt;
     int lda, ldb, ldc, M, N, K, ta, tb, acc, relu, tiles_m, tiles_n, ksplit, kgroups, block0;
 };
 struct TGroup { TProb p[TG_MAXP]; int n; };
@@ -359,6 +359,31 @@ __global__ __launch_bounds__(256) void k_tile_gemm(TGroup g) {
                 P.C[(size_t)gm * P.ldc + gn] = v;
             }
         }
+        // K > 256 with a tile counter: the workgroup that arrives last at the tile sums the slabs in slab order
+        // (same order, hence same bits, as k_tile_reduce) -- no second launch, no float atomics, no spinning.
+        if (P.kgroups > 1 && P.cnt) {
+            __threadfence();                                 // release this wave's slab
+            int old = 0;
+            if (lane == 0) old = atomicAdd(&P.cnt[rem], 1);
+            old = __shfl(old, 0, 64);
+            if (old == P.kgroups - 1) {
+                __threadfence();                             // acquire the other slabs
+                if (gn < P.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gm = m0 + row;
+                        if (gm >= P.M) continue;
+                        float v = 0.f;
+                        for (int q = 0; q < P.kgroups; ++q) v += __builtin_nontemporal_load(&P.part[((size_t)q * P.M + gm) * P.N + gn]);
+                        if (P.bias) v += P.bias[gn];
+                        if (P.relu) v = fmaxf(v, 0.f);
+                        if (P.acc) v += P.C[(size_t)gm * P.ldc + gn];
+                        P.C[(size_t)gm * P.ldc + gn] = v;
+                    }
+                }
+                if (lane == 0) P.cnt[rem] = 0;               // ready for the next launch
+            }
+        }
     }
 }
 
@@ -366,7 +391,7 @@ __global__ void k_tile_reduce(TGroup g) {
     int pi = blockIdx.y;
     if (pi >= g.n) return;
     const TProb& P = g.p[pi];
-    if (P.kgroups == 1) return;
+    if (P.kgroups == 1 || P.cnt) return;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.M * P.N) return;
     int m = t / P.N, n = t % P.N;
@@ -380,7 +405,9 @@ __global__ void k_tile_reduce(TGroup g) {
 
 /* desc: HOST array, 16 int64 per problem:
  *   [0] A  [1] B  [2] part scratch f32[ceil(K/256)][M][N] (needed when K > 256)  [3] C  [4] bias (0 = none)  [5] lda  [6] ldb  [7] ldc  [8] M  [9] N  [10] K
- *   [11] trans_a  [12] trans_b  [13] accumulate  [14] relu */
+ *   [11] trans_a  [12] trans_b  [13] accumulate  [14] relu
+ *   [15] tile counters i32[ceil(M/32)*ceil(N/32)] (0 = none): zero on first use, left zero by every launch; with them the
+ *        K > 256 slabs are summed by the last workgroup to reach each tile instead of by a second launch */
 extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream) {
     if (n_prob < 1 || n_prob > TG_MAXP || !desc) return EVAD_ERR_ARG;
     TGroup g;
@@ -391,13 +418,13 @@ extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream)
         TProb& P = g.p[i];
         P.A = (const float*)d[0]; P.B = (const float*)d[1]; P.part = (float*)d[2]; P.C = (float*)d[3]; P.bias = (const float*)d[4];
         P.lda = (int)d[5]; P.ldb = (int)d[6]; P.ldc = (int)d[7]; P.M = (int)d[8]; P.N = (int)d[9]; P.K = (int)d[10];
-        P.ta = (int)d[11]; P.tb = (int)d[12]; P.acc = (int)d[13]; P.relu = (int)d[14];
+        P.ta = (int)d[11]; P.tb = (int)d[12]; P.acc = (int)d[13]; P.relu = (int)d[14]; P.cnt = (int*)d[15];
         if (!P.A || !P.B || !P.C || P.M < 1 || P.N < 1 || P.K < 1 || (P.lda & 3) || (P.ldb & 3) || !al16(P.A) || !al16(P.B) ||
             P.ldc < P.N || P.lda < (P.ta ? P.M : P.K) || P.ldb < (P.tb ? P.K : P.N))
             return EVAD_ERR_ARG;
         P.tiles_m = (P.M + 31) / 32; P.tiles_n = (P.N + 31) / 32; P.ksplit = (P.K + 63) / 64; P.block0 = blocks;
         P.kgroups = (P.ksplit + 3) / 4;
-        if (P.kgroups > 1) { if (!P.part) return EVAD_ERR_ARG; if (P.M * P.N > max_mn) max_mn = P.M * P.N; }
+        if (P.kgroups > 1) { if (!P.part) return EVAD_ERR_ARG; if (!P.cnt && P.M * P.N > max_mn) max_mn = P.M * P.N; }
         blocks += P.tiles_m * P.tiles_n * P.kgroups;
     }
     hipLaunchKernelGGL(k_tile_gemm, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);

@@ -6,6 +6,7 @@ data-parallel all-reduce is ONE collective on `flat_grads`), workspace, and the 
 
 Row convention: R = B*32 rows, row = clip*32 + track slot (slots 0 and 31 are never valid)."""
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +31,9 @@ PARAMS = [
 
 def _rp(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+_TILE_CNT = os.environ.get("EVENTAD_TILE_CNT", "0") == "1"
 
 
 class NativeHead:
@@ -97,6 +101,7 @@ class NativeHead:
         # slabs for products with K > 256 (one scratch per grouped problem): ceil(K/256) x M x N floats; the largest are
         # the weight gradients (K = R rows, M x N = 768 x 256) and the chain's [32,768]x[768,256] (3 slabs of 32 x 256)
         w["part"] = [f(max(3 * 32 * 768, ((R + 255) // 256) * 768 * 256)) for _ in range(8)]
+        w["cnt"] = [i(24 * 24) for _ in range(8)]                               # tile counters of those products (<= 768 x 768 outputs)
         w["dwatt0"], w["dwatt1"] = f(256), f(256)                               # per-layer accumulators of d soft_attention.weight
         self._B = B
 
@@ -111,8 +116,11 @@ class NativeHead:
             acc = pr[13] if len(pr) > 13 else 0
             if K > 256 and ((K + 255) // 256) * M * N > self.w["part"][i].numel():
                 raise RuntimeError("grouped GEMM: split-K scratch too small for M=%d N=%d K=%d" % (M, N, K))
-            d[16 * i:16 * i + 15] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr() if K > 256 else 0, C.data_ptr(),
-                                     bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu]
+            if K > 256 and ((M + 31) // 32) * ((N + 31) // 32) > self.w["cnt"][i].numel():
+                raise RuntimeError("grouped GEMM: tile-counter buffer too small for M=%d N=%d" % (M, N))
+            d[16 * i:16 * i + 16] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr() if K > 256 else 0, C.data_ptr(),
+                                     bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu,
+                                     self.w["cnt"][i].data_ptr() if (K > 256 and _TILE_CNT) else 0]
         call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
 
     @staticmethod

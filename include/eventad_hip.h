@@ -185,7 +185,9 @@ int eventad_gru_att_bwd_group(int n_prob, const int64_t* desc, void* stream);
 /* Up to 8 independent small GEMMs per launch (one workgroup per 32x32 tile, its 4 waves split K in 64-deep
  * chunks and are summed in wave order = deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B
  * [2] part scratch f32[ceil(K/256)][M][N] (only when K > 256) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K
- * [11] trans_a [12] trans_b [13] accumulate [14] relu. */
+ * [11] trans_a [12] trans_b [13] accumulate [14] relu [15] tile counters i32[ceil(M/32)*ceil(N/32)] (0 = none; zero
+ * on first use, every launch leaves them zero): with them the slabs of a K > 256 product are summed, in slab order,
+ * by the last workgroup to reach the tile instead of by a second launch. */
 int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream);
 /* Up to 3 GRU cells per launch.  desc = HOST array, 12 int64 per cell: fwd [0] gi [1] gh [2] hprev [3] gates
  * [4] hnew [5] mask(0) [6] xdrop(0) [7] H; bwd [0] dhn [1] dx_extra(0) [2] mask(0) [3] gates [4] gh [5] hprev
