@@ -6,6 +6,7 @@ workspace ownership (torch tensors = device memory plumbing) and the sequence of
 No host<->device synchronisation happens inside `forward`; node and edge counts of the pooled
 graphs stay on the device (`n_dev`), so the whole forward is hipGraph-capturable."""
 import os
+import ctypes
 import torch
 
 from . import _lib, spline
@@ -87,9 +88,14 @@ class NativeBackbone:
         K = g.max_neighbors
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        # zero-initialised scratch of the event-level stage, back to back so eventad_sort_events clears it with ONE
+        # memset: [counters(4) | pixel histogram(P+1) | pool1 neighbour bitmap(3*S0)]
+        S0_ = g.grid[0][0] * g.grid[0][1] * (B + 1)
+        front_arena = torch.zeros(4 + P + 1 + 3 * S0_, dtype=torch.int32, device=dev)
         ws = dict(
-            counters=torch.zeros(4, dtype=torch.int32, device=dev),
-            key=i32(N), tq=i32(N), bev=i32(N), pix_count=i32(P + 1), pix_start=i32(P + 1),
+            front_arena=front_arena, counters=front_arena[:4], pix_count=front_arena[4:4 + P + 1],
+            bitmap0=front_arena[4 + P + 1:].view(S0_, 3),
+            key=i32(N), tq=i32(N), bev=i32(N), pix_start=i32(P + 1),
             scan_tmp=i32(max(P, 1 << 16) // 2048 + 4), sid_tmp=i32(N), sid=i32(N), long_list=i32(P),
             key_s=i32(N), ts_s=i32(N), ev2=i32(N, 2), posn_s=f32(N, 3), x0s=f32(N, 20),
             ell_src=i32(N, K), ell_step=torch.empty((N, K), dtype=torch.int16, device=dev), deg=i32(N),
@@ -117,7 +123,13 @@ class NativeBackbone:
             hands.append(H_)
         ws["hand"] = hands
         ws["scan_tmp_tail"] = i32(1 << 10)
-        ws["flags_tail"] = torch.zeros(4, dtype=torch.int32, device=dev)     # the tail stage may run concurrently with front
+        # zero-initialised scratch of the pooled stage (slot tables + neighbour bitmaps of pools 2..4, error flags): ONE
+        # fill at the start of tail() instead of two memsets per level.  (Separate from the front arena: the two
+        # stages may run concurrently on different batches.)
+        tail_words = sum(g.grid[lv][0] * g.grid[lv][1] * (B + 1) * (128 + 8 + 3) + 8 for lv in range(1, 4)) + 4
+        tail_arena = torch.zeros(tail_words, dtype=torch.int32, device=dev)
+        ws["tail_arena"], ws["flags_tail"] = tail_arena, tail_arena[tail_words - 4:]
+        toff = 0
         levels = []
         for lv in range(4):
             nx, ny = g.grid[lv]
@@ -127,12 +139,19 @@ class NativeBackbone:
             L = Level()
             L.nx, L.ny, L.S, L.C, L.ldx, L.n_max = nx, ny, S, C, ldx, S
             # slot tables back to back (feat | sums | tsum | cnt | maxidx) so the scatter path clears them with ONE memset
-            tab = torch.empty(S * (C + 8), dtype=torch.int32, device=dev)
+            if lv == 0:
+                tab = torch.empty(S * (C + 8), dtype=torch.int32, device=dev)     # pool_seg0 writes every slot: never cleared
+            else:
+                tab = tail_arena[toff: toff + S * (C + 8)]; toff += (S * (C + 8) + 3) // 4 * 4
             L.feat = tab[: S * C].view(S, C)
             L.sums = tab[S * C: S * C + 4 * S].view(torch.int64).view(S, 2)
             L.tsum = tab[S * C + 4 * S: S * C + 6 * S].view(torch.float64)
             L.cnt = tab[S * C + 6 * S: S * C + 7 * S]; L.maxidx = tab[S * C + 7 * S: S * C + 8 * S]
-            L.occ = i32(S + 1); L.slot2node = i32(S); L.bitmap = i32(S, 3)
+            L.occ = i32(S + 1); L.slot2node = i32(S)
+            if lv == 0:
+                L.bitmap = ws["bitmap0"]
+            else:
+                L.bitmap = tail_arena[toff: toff + 3 * S].view(S, 3); toff += (3 * S + 3) // 4 * 4
             L.node_slot = i32(S)
             if lv == 0:                                      # graph of level 0 = the front stage's hand-off (set A)
                 A_ = hands[0]
@@ -186,7 +205,7 @@ class NativeBackbone:
         pos = pos.contiguous().float()
         polarity = polarity.reshape(-1).contiguous().float()
         batch = batch.contiguous().long()
-        maps = []
+        maps, todo = [], []
         for i, m in enumerate(image_feats):
             m = m.contiguous().float()
             dst = hand.maps[i - 2] if i >= 2 else None     # maps 2..4 travel with the hand-off
@@ -199,22 +218,27 @@ class NativeBackbone:
                     assert tuple(dst.shape) == (m.shape[0], m.shape[2], m.shape[3], m.shape[1]), "unexpected CNN map size"
                 o = dst if dst is not None else torch.empty((m.shape[0], m.shape[2], m.shape[3], m.shape[1]),
                                                             dtype=torch.float32, device=m.device)
-                self._c("eventad_nchw_to_nhwc", ptr(m), ptr(o), m.shape[0], m.shape[1], m.shape[2], m.shape[3], st)
+                todo.append((m, o))
                 maps.append(o)
+        if todo:                                            # every NCHW -> NHWC layout change of the step in one launch
+            d = (ctypes.c_int64 * (6 * len(todo)))()
+            for i, (m, o) in enumerate(todo):
+                d[6 * i:6 * i + 6] = [m.data_ptr(), o.data_ptr(), m.shape[0], m.shape[1], m.shape[2], m.shape[3]]
+            self._c("eventad_nchw_to_nhwc_group", len(todo), ctypes.cast(d, ctypes.c_void_p), st)
         assert [m.shape[3] for m in maps] == FEATURE_CHANNELS and all(m.shape[0] == B for m in maps)
-        ws["counters"].zero_()
         w, K = self.w, g.max_neighbors
+        L0_ = ws["levels"][0]
         self._c("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
              N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
              ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["long_list"]), ptr(ws["counters"]),
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
-             ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), st)
+             ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), 3 * L0_.S, st)     # also clears counters, histogram, pool1 bitmap
         self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if (self.fused_mark or self.strip_width) else None,
              ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],
-             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, self.strip_width, st)
+             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, self.strip_width, 1, st)
         self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
              ptr(w["root1"]), ptr(w["bn1"][0]), ptr(w["bn1"][1]), ptr(ws["y1"]), N, g.steps, K, st)
         self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
@@ -251,7 +275,7 @@ class NativeBackbone:
         G0.x, G0.npos, G0.npix, G0.nbatch, G0.n_dev, G0.e_dev = hand.x, hand.npos, hand.npix, hand.nbatch, hand.n_dev, hand.e_dev
         G0.rowptr, G0.csr_src, G0.csr_dxy = hand.rowptr, hand.csr_src, hand.csr_dxy
         view = [G0] + levels[1:]
-        ws["flags_tail"].zero_()
+        ws["tail_arena"].zero_()
         out3 = None
         for lv in range(4):
             L = view[lv]
@@ -263,13 +287,13 @@ class NativeBackbone:
                 self._c("eventad_pool_scatter", _rp(Lp.y), 64, 64, _rp(fmap), fmap.shape[1], fmap.shape[2], 64,
                      _rp(Lp.npos), _rp(Lp.npix), _rp(Lp.nbatch), None, None, Lp.n_max, _rp(Lp.n_dev), g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
-                     ptr(Lp.node_slot_in), ptr(ws["flags_tail"]), st)
+                     ptr(Lp.node_slot_in), ptr(ws["flags_tail"]), 1, st)
                 self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), _rp(Lp.nbatch),
                      L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
                      ptr(ws["scan_tmp_tail"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
                      ptr(L.slot2node), ptr(L.n_dev), st)
                 self._c("eventad_pool_edges_mark_csr", _rp(Lp.rowptr), _rp(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
-                     _rp(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["flags_tail"]), st)
+                     _rp(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["flags_tail"]), 1, st)
                 self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
                      ptr(L.n_dev), L.nx, L.ny, ptr(L.rowptr), ptr(ws["scan_tmp_tail"]), ptr(L.csr_src), ptr(L.csr_dxy),
                      ptr(L.e_dev), st)

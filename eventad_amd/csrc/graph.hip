@@ -270,39 +270,6 @@ __global__ void k_scatter_events(const int* __restrict__ key, const unsigned* __
 // Order every pixel segment by event id (rank placement; ids are unique).  Short segments are
 // done by one thread; long ones are queued for the wave-cooperative kernel below.
 #define SEG_SHORT 32
-__global__ void k_order_short(const unsigned* __restrict__ start, const int* __restrict__ sid_tmp, int* __restrict__ sid,
-                              int P, int* __restrict__ long_list, unsigned* __restrict__ long_count) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    unsigned st = start[p], en = start[p + 1];
-    unsigned len = en - st;
-    if (len == 0) return;
-    if (len == 1) { sid[st] = sid_tmp[st]; return; }
-    if (len > SEG_SHORT) { long_list[atomicAdd(long_count, 1u)] = p; return; }
-    for (unsigned a = 0; a < len; ++a) {
-        int v = sid_tmp[st + a]; unsigned rank = 0;
-        for (unsigned c = 0; c < len; ++c) rank += (sid_tmp[st + c] < v);
-        sid[st + rank] = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_order_long(const unsigned* __restrict__ start, const int* __restrict__ sid_tmp,
-                                                    int* __restrict__ sid, const int* __restrict__ long_list,
-                                                    const unsigned* __restrict__ long_count) {
-    int lane = threadIdx.x & 63;
-    unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    unsigned n_long = *long_count;
-    for (unsigned w = wave; w < n_long; w += n_waves) {
-        int p = long_list[w];
-        unsigned st = start[p], len = start[p + 1] - st;
-        for (unsigned a = lane; a < len; a += 64) {
-            int v = sid_tmp[st + a]; unsigned rank = 0;
-            for (unsigned c = 0; c < len; ++c) rank += (sid_tmp[st + c] < v);
-            sid[st + rank] = v;
-        }
-    }
-}
-
 // Sorted-order event records + the 19(+1)-channel layer-1 input row
 //   x0s[r] = [polarity, 16 bilinear samples of CNN map 0, pos_x, pos_y, 0]   (reference net.py:116,122-123)
 // The sampler restates F.grid_sample(align_corners=True, zeros padding) as called by
@@ -318,7 +285,8 @@ __device__ __forceinline__ void bilinear_setup(float px_norm, float py_norm, flo
     *x0 = (int)fx0; *y0 = (int)fy0; *fx = ix - fx0; *fy = iy - fy0;
 }
 
-__global__ void k_gather_sorted(const int* __restrict__ sid, const int* __restrict__ key, const int* __restrict__ tq,
+__global__ void k_gather_sorted(const int* __restrict__ sid_tmp, const unsigned* __restrict__ start, int* __restrict__ sid,
+                                const int* __restrict__ key, const int* __restrict__ tq,
                                 const float* __restrict__ pos, const float* __restrict__ pol,
                                 const float* __restrict__ map0 /* NHWC [B,h,w,16] */, int h_in, int w_in,
                                 int N, int W, int H, int* __restrict__ key_s, int* __restrict__ ts_s, int2* __restrict__ ev2,
@@ -326,10 +294,23 @@ __global__ void k_gather_sorted(const int* __restrict__ sid, const int* __restri
                                 float vsx, float vsy, int nx, int ny, int S, const int* __restrict__ px_to_cx,
                                 const int* __restrict__ py_to_cy, int* __restrict__ node_slot, int* __restrict__ node_vox,
                                 int* __restrict__ ovf_list, unsigned* __restrict__ counters) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
-    int i = sid[r];
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    // Thread t owns the event the counting sort dropped at (unordered) slot t of its pixel segment; its final
+    // position is segment start + its id rank inside the segment (FIFO order = ascending id).  Ranking here
+    // replaces two ordering launches; a segment of length L costs L loads per thread (L = 1..3 typically).
+    int i = sid_tmp[t];
     int k = key[i];
+    int r = t;
+    {
+        unsigned s0 = start[k], s1 = start[k + 1];
+        if (s1 - s0 > 1) {
+            unsigned rank = 0;
+            for (unsigned c = s0; c < s1; ++c) rank += (sid_tmp[c] < i);
+            r = (int)(s0 + rank);
+        }
+    }
+    sid[r] = i;
     key_s[r] = k; ts_s[r] = tq[i];
     if (ev2) ev2[r] = make_int2(i, tq[i]);
     float px = pos[3 * i], py = pos[3 * i + 1], pt = pos[3 * i + 2];
@@ -384,16 +365,22 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
                                    uint32_t* counters /* [0]=flags [1]=long_count */,
                                    int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s,
                                    float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
-                                   int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, void* stream) {
-    if (!pos || !batch || !polarity || !map0_nhwc || !key || !tq || !bev || !pix_count || !pix_start || !scan_tmp ||
+                                   int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words, void* stream) {
+    if (zero_tail_words < 0 || !pos || !batch || !polarity || !map0_nhwc || !key || !tq || !bev || !pix_count || !pix_start || !scan_tmp ||
         !sid_tmp || !sid || !long_list || !counters || !key_s || !ts_s || !posn_s || !x0s ||
         N < 0 || B <= 0 || W <= 0 || H <= 0 || T <= 0 || map_h <= 0 || map_w <= 0)
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     long long P = (long long)B * H * W;
     if (P >= (1ll << 31)) return EVAD_ERR_ARG;
-    hipMemsetAsync(pix_count, 0, sizeof(uint32_t) * (P + 1), st);
-    hipMemsetAsync(counters + 1, 0, 3 * sizeof(uint32_t), st);
+    // counters (all four words: this is the first call of a step), the pixel histogram and -- when the caller laid
+    // them out back to back -- `zero_tail_words` more words behind it (the step's other zero-initialised scratch)
+    if (counters + 4 == pix_count) hipMemsetAsync(counters, 0, sizeof(uint32_t) * (4 + P + 1 + (size_t)zero_tail_words), st);
+    else {
+        if (zero_tail_words) return EVAD_ERR_ARG;
+        hipMemsetAsync(pix_count, 0, sizeof(uint32_t) * (P + 1), st);
+        hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), st);
+    }
     if (node_slot && (!px_to_cx || !py_to_cy || !ovf_list || !node_vox || nx <= 0 || ny <= 0 || vsx <= 0 || vsy <= 0)) return EVAD_ERR_ARG;
     if (N > 0)
         hipLaunchKernelGGL(k_prep_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, pos, (const long long*)batch, N, B,
@@ -402,10 +389,7 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     if (rc) return rc;
     if (N == 0) return evad_last_error();
     hipLaunchKernelGGL(k_scatter_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, pix_count, sid_tmp, N, counters + 3);
-    hipLaunchKernelGGL(k_order_short, dim3(evad_blocks(P, 256)), dim3(256), 0, st, pix_start, sid_tmp, sid, (int)P,
-                       long_list, counters + 1);
-    hipLaunchKernelGGL(k_order_long, dim3(512), dim3(256), 0, st, pix_start, sid_tmp, sid, long_list, counters + 1);
-    hipLaunchKernelGGL(k_gather_sorted, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid, key, tq, pos, polarity,
+    hipLaunchKernelGGL(k_gather_sorted, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid_tmp, pix_start, sid, key, tq, pos, polarity,
                        map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, (int2*)ev2, posn_s, x0s, vsx, vsy, nx, ny, nx * ny * (B + 1),
                        px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, counters);
     return evad_last_error();
@@ -1137,13 +1121,13 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
                                  const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
                                  int32_t* deg, const int32_t* node_slot, const int32_t* node_vox, int nx, int ny,
-                                 uint32_t* bitmap, int strip_width, void* stream) {
+                                 uint32_t* bitmap, int strip_width, int bitmap_prezeroed, void* stream) {
     if (!sid || !ts_s || !key_s || !pix_start || !counters || !ell_src || !ell_step || !deg || N < 0 || B <= 0 ||
         W <= 0 || H <= 0 || radius_px < 0 || max_num_neighbors < 1 || max_num_neighbors > 65535 || queue_size < 1 ||
         (bitmap && (!node_slot || !node_vox || nx <= 0 || ny <= 0 || nx > 255 || ny > 255)))
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (bitmap) hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    if (bitmap && !bitmap_prezeroed) hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
     if (N == 0) return evad_last_error();
     int steps;
     if (ensure_spiral(radius_px, st, &steps)) return -2;

@@ -136,7 +136,7 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
                                     const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx,
                                     float vsy, int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums,
                                     double* tsum, uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags,
-                                    void* stream) {
+                                    int prezeroed, void* stream) {
     if (!xa || !npos || !feat || !sums || !tsum || !cnt || !maxidx || !node_slot || !flags || (!key_s && (!npix || !nbatch)) ||
         (Cm > 0 && !map_nhwc) || Ca < 0 || Cm < 0 || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0 || vsx <= 0 || vsy <= 0)
         return EVAD_ERR_ARG;
@@ -144,7 +144,8 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
     int S = nx * ny * (B + 1), C = Ca + Cm;
     // one memset when the caller laid the tables out back to back (feat | sums | tsum | cnt | maxidx), else five
     const char* f0 = (const char*)feat; const size_t nf = sizeof(uint32_t) * (size_t)S * C;
-    if ((const char*)sums == f0 + nf && (const char*)tsum == (const char*)sums + 16 * (size_t)S &&
+    if (prezeroed) {}                                        // the caller zeroed the tables (one memset for all levels)
+    else if ((const char*)sums == f0 + nf && (const char*)tsum == (const char*)sums + 16 * (size_t)S &&
         (const char*)cnt == (const char*)tsum + 8 * (size_t)S && (const char*)maxidx == (const char*)cnt + 4 * (size_t)S)
         hipMemsetAsync(feat, 0, nf + 32 * (size_t)S, st);
     else {
@@ -294,18 +295,27 @@ __global__ void k_occupancy(const unsigned* __restrict__ cnt, unsigned* __restri
     if (s < S) occ[s] = cnt[s] > 0 ? 1u : 0u;
 }
 
-__global__ void k_finalize_nodes(const unsigned* __restrict__ occ_scan, const unsigned* __restrict__ cnt,
-                                 const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ tsum,
-                                 const int* __restrict__ maxidx, const int* __restrict__ batch_of_index, int S, int level0,
-                                 float Wf, float Hf, float whx, float why, int C, int ldx, float* __restrict__ xout,
-                                 float* __restrict__ npos, int* __restrict__ npix, int* __restrict__ nbatch,
-                                 int* __restrict__ node_slot_out, int* __restrict__ slot2node, int* __restrict__ n_out) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0) *n_out = (int)occ_scan[S];
-    if (s >= S) return;
+// One launch for node attributes + features: thread (slot s, channel c) writes channel c of the slot's node; the
+// c == 0 thread also writes the node's position / pixel / clip and the pos channels of x (two dependent small
+// launches cost ~4.5 us each inside a replayed graph -- more than the work of a pooled level).
+template <int MODE>      // 0: ordered-uint max, 1: float sum -> mean, 2: float max
+__global__ void k_finalize(const unsigned* __restrict__ occ_scan, const unsigned* __restrict__ cnt,
+                           const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ tsum,
+                           const int* __restrict__ maxidx, const int* __restrict__ batch_of_index,
+                           const unsigned* __restrict__ feat, int S, int level0, float Wf, float Hf, float whx, float why, int C,
+                           int ldx, float* __restrict__ xout, float* __restrict__ npos, int* __restrict__ npix,
+                           int* __restrict__ nbatch, int* __restrict__ node_slot_out, int* __restrict__ slot2node,
+                           int* __restrict__ n_out) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *n_out = (int)occ_scan[S];
+    if (t >= (long long)S * C) return;
+    int s = (int)(t / C), ch = (int)(t % C);
     unsigned c = cnt[s];
-    if (c == 0) { slot2node[s] = -1; return; }
+    if (c == 0) { if (ch == 0) slot2node[s] = -1; return; }
     int j = (int)occ_scan[s];
+    float v = MODE == 1 ? __fdiv_rn(__uint_as_float(feat[t]), (float)c) : (MODE == 2 ? __uint_as_float(feat[t]) : evad_ord2f(feat[t]));
+    xout[(size_t)j * ldx + ch] = v;
+    if (ch != 0) return;
     slot2node[s] = j; node_slot_out[j] = s;
     // pool_pos: mean of the members' normalised positions.  Level 0: pos = px/W; pooled levels:
     // pos = q * (1/W) (round_to_pixel).  Integer pixel sums make the mean order independent.
@@ -325,18 +335,6 @@ __global__ void k_finalize_nodes(const unsigned* __restrict__ occ_scan, const un
     for (int k = C + 2; k < ldx; ++k) xout[(size_t)j * ldx + k] = 0.f;
 }
 
-template <int MODE>      // 0: ordered-uint max, 1: float sum -> mean, 2: float max
-__global__ void k_finalize_feat(const unsigned* __restrict__ feat, const unsigned* __restrict__ cnt,
-                                const int* __restrict__ slot2node, int S, int C, int ldx, float* __restrict__ xout) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)S * C) return;
-    int s = (int)(t / C), c = (int)(t % C);
-    int j = slot2node[s];
-    if (j < 0) return;
-    float v = MODE == 1 ? __fdiv_rn(__uint_as_float(feat[t]), (float)cnt[s]) : (MODE == 2 ? __uint_as_float(feat[t]) : evad_ord2f(feat[t]));
-    xout[(size_t)j * ldx + c] = v;
-}
-
 extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const double* tsum, const uint32_t* cnt,
                                      const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
                                      int feat_mode, int level0, int W, int H, float wh_inv_x, float wh_inv_y,
@@ -344,7 +342,7 @@ extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums,
                                      int32_t* npix_out, int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node,
                                      int32_t* n_out_dev, void* stream) {
     if (!feat || !sums || !tsum || !cnt || !maxidx || !batch_of_index || !occ_scan || !scan_tmp || !xout || !npos_out ||
-        !npix_out || !nbatch_out || !node_slot_out || !slot2node || !n_out_dev || ldx < C + 2 || nx <= 0 || ny <= 0 || B <= 0)
+        !npix_out || !nbatch_out || !node_slot_out || !slot2node || !n_out_dev || C < 1 || ldx < C + 2 || nx <= 0 || ny <= 0 || B <= 0)
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int S = nx * ny * (B + 1);
@@ -355,13 +353,12 @@ extern "C" int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums,
         int rc = evad_exclusive_scan(occ_scan, occ_scan, scan_tmp, S, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_finalize_nodes, dim3(evad_blocks(S, 256)), dim3(256), 0, st, occ_scan, cnt,
-                       (const unsigned long long*)sums, (const unsigned long long*)tsum, maxidx, batch_of_index, S, level0, (float)W, (float)H,
-                       wh_inv_x, wh_inv_y, C, ldx, xout, npos_out, npix_out, nbatch_out, node_slot_out, slot2node, n_out_dev);
     dim3 grid(evad_blocks((long long)S * C, 256));
-    if (feat_mode == 1)      hipLaunchKernelGGL(k_finalize_feat<1>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
-    else if (feat_mode == 2) hipLaunchKernelGGL(k_finalize_feat<2>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
-    else                     hipLaunchKernelGGL(k_finalize_feat<0>, grid, dim3(256), 0, st, feat, cnt, slot2node, S, C, ldx, xout);
+#define EVAD_FIN(MODE) hipLaunchKernelGGL(k_finalize<MODE>, grid, dim3(256), 0, st, occ_scan, cnt, (const unsigned long long*)sums, \
+                       (const unsigned long long*)tsum, maxidx, batch_of_index, feat, S, level0, (float)W, (float)H, wh_inv_x, wh_inv_y, \
+                       C, ldx, xout, npos_out, npix_out, nbatch_out, node_slot_out, slot2node, n_out_dev)
+    if (feat_mode == 1) EVAD_FIN(1); else if (feat_mode == 2) EVAD_FIN(2); else EVAD_FIN(0);
+#undef EVAD_FIN
     return evad_last_error();
 }
 
@@ -464,11 +461,11 @@ extern "C" int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t
 
 extern "C" int eventad_pool_edges_mark_csr(const uint32_t* rowptr, const int32_t* csr_src, const int32_t* node_slot,
                                            int n_max, const int32_t* n_dev, int nx, int ny, int B, uint32_t* bitmap,
-                                           uint32_t* flags, void* stream) {
+                                           uint32_t* flags, int prezeroed, void* stream) {
     if (!rowptr || !csr_src || !node_slot || !n_dev || !bitmap || !flags || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0)
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    if (!prezeroed) hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
     if (n_max > 0)
         hipLaunchKernelGGL(k_mark_csr, dim3(evad_blocks(n_max, 16)), dim3(256), 0, st, rowptr, csr_src, node_slot, n_max,
                            n_dev, nx, ny, bitmap, flags);

@@ -92,3 +92,54 @@ extern "C" int eventad_nchw_to_nhwc(const float* in, float* out, int B, int C, i
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(evad_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, total);
     return evad_last_error();
 }
+
+// All (up to 8) map layout changes of a step in ONE launch, as 32x32 LDS-tiled transposes (coalesced on both sides;
+// the per-element kernel above reads with a stride of H*W floats).  desc: HOST array, 6 int64 per map:
+// [0] in [1] out [2] B [3] C [4] H [5] W.
+struct TrMap { const float* in; float* out; int C, P, tiles_c, tiles_p, block0; };
+struct TrGroup { TrMap m[8]; int n; };
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc_group(TrGroup g) {
+    __shared__ float tile[32][33];
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.m[i].block0) mi = i;
+    const TrMap& M = g.m[mi];
+    int local = blockIdx.x - M.block0;
+    const int per_b = M.tiles_c * M.tiles_p;
+    const int b = local / per_b, rem = local % per_b, tc = rem / M.tiles_p, tp = rem % M.tiles_p;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* in = M.in + (size_t)b * M.C * M.P;
+    float* out = M.out + (size_t)b * M.C * M.P;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                           // read: rows = channels, lanes = pixels
+        int c = tc * 32 + ty + 8 * r, p = tp * 32 + tx;
+        if (c < M.C && p < M.P) tile[ty + 8 * r][tx] = in[(size_t)c * M.P + p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                           // write: rows = pixels, lanes = channels
+        int p = tp * 32 + ty + 8 * r, c = tc * 32 + tx;
+        if (c < M.C && p < M.P) out[(size_t)p * M.C + c] = tile[tx][ty + 8 * r];
+    }
+}
+
+extern "C" int eventad_nchw_to_nhwc_group(int n, const int64_t* desc, void* stream) {
+    if (n < 1 || n > 8 || !desc) return EVAD_ERR_ARG;
+    TrGroup g; g.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* d = desc + 6 * i;
+        TrMap& M = g.m[i];
+        M.in = (const float*)d[0]; M.out = (float*)d[1];
+        long long B = d[2], C = d[3], P = d[4] * d[5];
+        if (!M.in || !M.out || B < 0 || C <= 0 || P <= 0 || B * C * P > (1ll << 31)) return EVAD_ERR_ARG;
+        M.C = (int)C; M.P = (int)P; M.tiles_c = (int)((C + 31) / 32); M.tiles_p = (int)((P + 31) / 32); M.block0 = blocks;
+        long long nb = B * M.tiles_c * M.tiles_p;
+        if (blocks + nb > (1ll << 30)) return EVAD_ERR_ARG;
+        blocks += (int)nb;
+    }
+    if (blocks == 0) return EVAD_OK;
+    hipLaunchKernelGGL(k_nchw_to_nhwc_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}

@@ -54,9 +54,12 @@ int eventad_spiral_offsets(int radius, int16_t* dxdy);
  *   in : pos f32[N,3] normalised, batch i64[N], polarity f32[N], map0 f32[B,h,w,16] (NHWC)
  *   out: key/tq/bev i32[N] (event order: pixel key, t in us, clip), pix_start u32[B*H*W+1],
  *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], ev2 i32[N,2] = {id, t} pairs (nullable), posn_s f32[N,3], x0s f32[N,20]
- *   ws : pix_count u32[B*H*W+1], scan_tmp u32[B*H*W/2048+2], sid_tmp i32[N], long_list i32[B*H*W],
- *        counters u32[4] ([0] = EVENTAD_FLAG_* bits, caller zeroes it; [1] internal; [2] = length of ovf_list;
- *        [3] = longest pixel segment of the batch)
+ *   ws : pix_count u32[B*H*W+1], scan_tmp u32[B*H*W/2048+2], sid_tmp i32[N], long_list (reserved, unused),
+ *        counters u32[4], zeroed by this call -- the first of a step ([0] = EVENTAD_FLAG_* bits, accumulated by the
+ *        later stages; [1] unused; [2] = length of ovf_list; [3] = longest pixel segment of the batch).
+ *        When pix_count == counters + 4 the two are cleared by ONE memset, which then also covers the
+ *        zero_tail_words u32 words behind pix_count (the caller's other zero-initialised scratch of the step,
+ *        e.g. the pool1 bitmap); zero_tail_words must be 0 otherwise.
  *   pool1 prep (node_slot nullable = skip): node_slot i32[N] = voxel slot of each sorted event computed from its
  *        float position as grid_cluster does (pooling.py:55-56); px_to_cx i32[W] / py_to_cy i32[H] = voxel of a
  *        pixel; node_vox i32[N] = the slot decomposed as cx | cy<<8 | plane<<16; events whose slot differs from their pixel's (t == time_window, off-grid positions) -> ovf_list */
@@ -65,7 +68,8 @@ int eventad_sort_events(const float* pos, const int64_t* batch, const float* pol
                         int32_t* bev, uint32_t* pix_count, uint32_t* pix_start, uint32_t* scan_tmp, int32_t* sid_tmp,
                         int32_t* sid, int32_t* long_list, uint32_t* counters, int32_t* key_s, int32_t* ts_s, int32_t* ev2,
                         float* posn_s, float* x0s, float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx,
-                        const int32_t* py_to_cy, int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, void* stream);
+                        const int32_t* py_to_cy, int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words,
+                        void* stream);
 /* eventad_build_ell: the edge search of ev_graph.cu:15-80 over the pixel CSR.  ELL adjacency in
  * pixel-sorted numbering: ell_src i32[N,K] (slot 0 = self edge), ell_step u16[N,K] (spiral step =
  * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
@@ -73,12 +77,12 @@ int eventad_sort_events(const float* pos, const int64_t* batch, const float* pol
  * strip_width (needs ev2): > 0 LDS-staged search, one wave per strip of that many pixels of a sensor row;
  * 0 batched prefetch; -1 thread per event, row in registers (default); -2 row-parallel; -3 wave per event with
  * binary-searched ranges; -4 converged lanes with fixed-trip binary searches; -5 the same over LDS-staged row
- * strips.  All variants give identical rows. */
+ * strips.  All variants give identical rows.  bitmap_prezeroed != 0: the caller already cleared the bitmap. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                       int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step, int32_t* deg,
                       const int32_t* node_slot, const int32_t* node_vox, int nx, int ny, uint32_t* bitmap, int strip_width,
-                      void* stream);
+                      int bitmap_prezeroed, void* stream);
 /* ELL -> the reference's edge buffer layout (i64[2,K], event numbering, -1 padded). */
 int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32_t* sid, int N, int max_num_neighbors,
                          int64_t K, int64_t* edges, void* stream);
@@ -99,12 +103,13 @@ int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t* ell_src, 
 /* ---- (D) sampling_skip + Pooling.forward: replaces net.py:15-17,200-228 + pooling.py:51-97 ------ */
 /* Slot table over S = nx*ny*(B+1) voxel slots: feat u32[S,Ca+Cm], sums u64[S,2], tsum 8 bytes[S] (2^-40 fixed point),
  * cnt u32[S], maxidx i32[S].  Level 0 passes key_s (pixel keys) and nidx = sid; pooled levels pass
- * npix/nbatch and n_dev (device-side node count). */
+ * npix/nbatch and n_dev (device-side node count).  The tables are cleared first unless prezeroed != 0 (the caller
+ * cleared them, e.g. with one memset over the tables of every level). */
 int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
                          const float* npos, const int32_t* npix, const int32_t* nbatch, const int32_t* key_s,
                          const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx, float vsy,
                          int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums, double* tsum,
-                         uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, void* stream);
+                         uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, int prezeroed, void* stream);
 /* Level-0 pooling without atomics: one wave per voxel slot walks the slot's pixel rows in the pixel CSR
  * (events of a voxel row are contiguous in sorted order), samples the 64-channel CNN map per member and
  * keeps running maxima in registers.  vx_lo i32[nx+1] / vy_lo i32[ny+1] = first pixel of each voxel column
@@ -125,7 +130,7 @@ int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t* deg, cons
                                 void* stream);
 int eventad_pool_edges_mark_csr(const uint32_t* rowptr, const int32_t* csr_src, const int32_t* node_slot, int n_max,
                                 const int32_t* n_dev, int nx, int ny, int B, uint32_t* bitmap, uint32_t* flags,
-                                void* stream);
+                                int prezeroed, void* stream);
 int eventad_pool_edges_emit(const uint32_t* bitmap, const int32_t* node_slot_out, const int32_t* slot2node,
                             const int32_t* npix_out, int n_max_out, const int32_t* n_out_dev, int nx, int ny,
                             uint32_t* rowptr, uint32_t* scan_tmp, int32_t* csr_src, int32_t* csr_dxy,
@@ -142,6 +147,9 @@ int eventad_tail_blend(const float* Z, int ldz, int root_col, const float* Zskip
                        const int32_t* n_dev, float div_x, float div_y, const float* bn_scale, const float* bn_shift,
                        const float* skip_scale, const float* skip_shift, float* out, int ldo, void* stream);
 int eventad_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream);
+/* The same for up to 8 maps in one launch (LDS-tiled transposes).  desc = HOST array, 6 int64 per map:
+ * [0] in [1] out [2] B [3] C [4] H [5] W. */
+int eventad_nchw_to_nhwc_group(int n_maps, const int64_t* desc, void* stream);
 
 /* ---- (F) EventAD head --------------------------------------------------------------------------- */
 /* ROI pooling of out4 node features per box: replaces EventADModel.extract_features' box loop and

@@ -34,13 +34,13 @@ def timeit(fn, it=30):
 def ell(bitmap, sw=0):
     call("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["key_s"]), ptr(ws["pix_start"]),
          ptr(ws["counters"]), N, B, g.W, g.H, g.radius_px, g.delta_t_us, 16, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]),
-         ptr(ws["deg"]), ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1], bitmap, sw, st)
+         ptr(ws["deg"]), ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1], bitmap, sw, 0, st)
 
 
 def ell_old():
     call("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), None, ptr(ws["key_s"]), ptr(ws["pix_start"]),
          ptr(ws["counters"]), N, B, g.W, g.H, g.radius_px, g.delta_t_us, 16, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]),
-         ptr(ws["deg"]), None, None, g.grid[0][0], g.grid[0][1], None, 0, st)
+         ptr(ws["deg"]), None, None, g.grid[0][0], g.grid[0][1], None, 0, 0, st)
 
 
 print("N", N, "E", int(ws["deg"].sum()), "max deg", int(ws["deg"].max()), "deg==16 frac", float((ws["deg"] == 16).float().mean()))

@@ -32,7 +32,9 @@ def main():
         for _ in range(10): g.replay()
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(n): g.replay()
+        cpu = (time.perf_counter() - t) / n * 1e3               # host time to enqueue one replay
         torch.cuda.synchronize()
+        print("  host enqueue %.3f ms/replay" % cpu)
         return (time.perf_counter() - t) / n * 1e3
     def bb():
         with torch.no_grad():
@@ -42,10 +44,15 @@ def main():
             model._head_native(step._feats_cur, data, labels)
             step.nh.backward()
             step.nh.optimizer_step()
-    print("backbone + ROI graph : %.3f ms" % timeit(bb))
-    print("head update graph    : %.3f ms" % timeit(head))
-    print("sequential step graph: %.3f ms" % timeit(lambda: step.step(data, labels)))
-    print("pipelined step graph : %.3f ms" % timeit(lambda: step.pipelined_step(data, labels, data)))
+    which = sys.argv[2] if len(sys.argv) > 2 else "backbone"     # ONE capture per process (several large graphs in
+    if which == "backbone":                                      # one process have crashed the HIP runtime here)
+        print("backbone + ROI graph : %.3f ms" % timeit(bb))
+    elif which == "head":
+        print("head update graph    : %.3f ms" % timeit(head))
+    elif which == "sequential":
+        print("sequential step graph: %.3f ms" % timeit(lambda: step.step(data, labels)))
+    else:
+        print("pipelined step graph : %.3f ms" % timeit(lambda: step.pipelined_step(data, labels, data)))
 
 if __name__ == "__main__":
     main()
