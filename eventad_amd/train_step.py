@@ -173,6 +173,62 @@ class TrainStep:
         self._feats_cur.copy_(feats_next)
         return loss, norm
 
+    # ---- the same two-stage pipeline as TWO single-branch hipGraphs replayed on two streams.  A single graph with
+    # parallel branches costs ~1.3 ms of HOST time per replay on this runtime (single-branch graphs enqueue in
+    # ~0.04 ms), but measured end to end the two-graph form is no faster (C2: 1.50 vs 1.43 ms per step): with two
+    # queues of small dependent kernels the step is bound by the command processor's per-dispatch latency
+    # (~4.5 us), not by the host.  Kept as an option.  Per step:   stream H: wait(backbone k done); feats_cur <- feats_next; head graph(k)
+    #                                   stream G: wait(copy done);       backbone graph(k+1)
+    def capture_dual(self, data, labels=None, warmup=3, data_next=None):
+        assert self.native, "graph capture is for the GPU path"
+        if labels is None:
+            labels = data.bbox[:, 4]
+        data_next = data_next or data
+        self.prime(data)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.pipelined_step(data, labels, data_next)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._retired = getattr(self, "_retired", []) + [g for g in (getattr(self, "_gb", None), getattr(self, "_gh", None)) if g is not None]
+        self._gb, self._gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            with torch.cuda.graph(self._gb, capture_error_mode="thread_local"):
+                self._feats_next = self.model.extract_features(data_next, frames=(1,))
+            with torch.cuda.graph(self._gh, capture_error_mode="thread_local"):
+                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data, labels)
+                self.nh.backward()
+                if self.world > 1:
+                    dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
+                norm = self.nh.optimizer_step()
+        self._g_loss, self._g_norm = loss, norm
+        self._ev_b, self._ev_c = torch.cuda.Event(), torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        self._sg.wait_stream(main)
+        with torch.cuda.stream(self._sg):                      # features of the first batch, as prime() left them
+            self._gb.replay()
+            self._ev_b.record(self._sg)
+        self.graph = None
+        return self._gb, self._gh
+
+    def replay_dual(self):
+        main = torch.cuda.current_stream()
+        sg, sh = self._sg, self._sh
+        sg.wait_stream(main); sh.wait_stream(main)
+        with torch.cuda.stream(sh):
+            sh.wait_event(self._ev_b)
+            self._feats_cur.copy_(self._feats_next)
+            self._ev_c.record(sh)
+            self._gh.replay()
+        with torch.cuda.stream(sg):
+            sg.wait_event(self._ev_c)
+            self._gb.replay()
+            self._ev_b.record(sg)
+        main.wait_stream(sg); main.wait_stream(sh)
+        return self._g_loss, self._g_norm
+
     # ---- three-stage pipeline: front(batch k+2) || tail + ROI(batch k+1) || head update(batch k).
     # The backbone itself is split at its flat hand-off (eventad_amd/backbone.py): the event-level stage and
     # the pooled stage are both chains of small dependent launches, so overlapping them hides launch latency.
