@@ -102,7 +102,10 @@ class NativeHead:
         # the weight gradients (K = R rows, M x N = 768 x 256) and the chain's [32,768]x[768,256] (3 slabs of 32 x 256)
         w["part"] = [f(max(3 * 32 * 768, ((R + 255) // 256) * 768 * 256)) for _ in range(8)]
         w["cnt"] = [i(24 * 24) for _ in range(8)]                               # tile counters of those products (<= 768 x 768 outputs)
-        w["dwatt0"], w["dwatt1"] = f(256), f(256)                               # per-layer accumulators of d soft_attention.weight
+        w["dwatt"] = f(2, 256)                                                  # per-layer accumulators of d soft_attention.weight
+        w["dwatt0"], w["dwatt1"] = w["dwatt"][0], w["dwatt"][1]
+        w["zero256"], w["zero32"] = f(NT, 256), f(NT, 32)
+        w["D"] = f(2 * R, 256)                                                  # dropout masks (GRU inter-layer | fusion)
         self._B = B
 
     # ------------------------------------------------------------ launch helpers
@@ -142,7 +145,7 @@ class NativeHead:
              torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train):
+    def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train, lean=False):
         """feats f32[B,2,31,64] (ROI features), bbox f32[M,6], bbox_batch i64[M], labels f32[M] or None.
         Returns (loss 0-d, logits [B,32,2], valid bool[B,32], targets i64[B,32]); keeps what backward needs."""
         self._alloc(B)
@@ -156,15 +159,15 @@ class NativeHead:
         call("eventad_head_tables", _rp(bbox_c), _rp(bb_c), M, _rp(lab_c), ptr(feats), B, int(width), int(height),
              ptr(w["X"]), ptr(w["CO"]), ptr(w["target"]), ptr(w["valid"]), st)
         self.D1 = self.D2 = None
-        if train:                                              # nn.GRU(dropout=.3) between layers; fusion Dropout(.3)
-            self.D1 = torch.bernoulli(torch.full((R, 256), 0.7, device=self.dev)) / 0.7
-            self.D2 = torch.bernoulli(torch.full((R, 256), 0.7, device=self.dev)) / 0.7
+        if train:                                              # nn.GRU(dropout=.3) between layers; fusion Dropout(.3):
+            w["D"].bernoulli_(0.7).div_(0.7)                   # both masks in two launches
+            self.D1, self.D2 = w["D"][:R], w["D"][R:]
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
         # input projections of every clip at once
         self._gg((0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, P[ev + "bias_ih_l0"]),
                  (0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, P[co + "bias_ih_l0"]))
-        w["S0"][:NT].zero_(); w["S1"][:NT].zero_(); w["SC"][:NT].zero_()
+        # rows [0, NT) of S0/S1/SC are the initial hidden state: zero at allocation and never written
         # The clip-to-clip hidden-state chain (EventAD.py:211-323) as a wavefront: stage b runs GRU layer 0 and the
         # coordinate GRU on clip b and GRU layer 1 on clip b-1 (its input, the dropout'd layer-0 output of clip
         # b-1, and its state, the layer-1 attention of clip b-2, are both a stage old), so one stage is two
@@ -195,6 +198,8 @@ class NativeHead:
         call("eventad_fuse_out", ptr(w["F1r"]), _rp(self.D2), _rp(P[fu + "fusion.3.weight"]), _rp(P[fu + "fusion.3.bias"]),
              ptr(w["target"]), ptr(w["valid"]), R, ptr(w["logits"]), ptr(w["dlog"]), ptr(w["loss_rows"]), ptr(w["loss"]), st)
         self._fw = (B, train)
+        if lean:                                               # training loop: no dtype conversions (3 launches less)
+            return (w["loss"][0], w["logits"].view(B, NT, 2), w["valid"].view(B, NT), w["target"].view(B, NT))
         return (w["loss"][0], w["logits"].view(B, NT, 2), w["valid"].view(B, NT).bool(), w["target"].view(B, NT).long())
 
     # ----------------------------------------------------------------- backward
@@ -217,12 +222,14 @@ class NativeHead:
                  (0, 0, dC, 512, P[fu + "coord_proj.weight"], 32, w["dHCo"], 32, R, 32, 256))
         self._desc("eventad_colsum_group", 4, [[w["dPre"], G[fu + "fusion.0.bias"], 256, 256], [dE, G[fu + "event_proj.bias"], 512, 256],
                                                [dC, G[fu + "coord_proj.bias"], 512, 256]], R)
-        d0, d1, dc = w["dS0a"], w["dS1a"], w["dSCa"]
-        n0, n1, nc = w["dS0b"], w["dS1b"], w["dSCb"]
-        d0.zero_(); d1.zero_(); dc.zero_()
+        # dS of the state after the last clip is zero: a constant zero buffer read by the first stage of each chain
+        # (z* are never written), then the a/b buffers alternate
+        d0, d1, dc = w["zero256"], w["zero256"], w["zero32"]
+        n0, n1, nc = w["dS0a"], w["dS1a"], w["dSCa"]
+        o0, o1, oc = w["dS0b"], w["dS1b"], w["dSCb"]
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
         gattc = G["soft_attention_cor.weight"]
-        w["dwatt0"].zero_(); w["dwatt1"].zero_()
+        w["dwatt"].zero_()
         # reverse wavefront: stage b runs layer 1 + the coordinate GRU on clip b and layer 0 on clip b+1 (whose
         # dX1 and dS0 come out of the previous stage's GEMMs): fused attention+cell backward, then one grouped GEMM
         for b in range(B - 1, -2, -1):
@@ -246,10 +253,10 @@ class NativeHead:
             self._desc("eventad_gru_att_bwd_group", 16, steps)
             self._gg(*gemms)
             if b >= 0:
-                d1, n1 = n1, d1
-                dc, nc = nc, dc
+                d1, n1, o1 = n1, o1, n1
+                dc, nc, oc = nc, oc, nc
             if b + 1 < B:
-                d0, n0 = n0, d0
+                d0, n0, o0 = n0, o0, n0
         torch.add(w["dwatt0"], w["dwatt1"], out=G["soft_attention.weight"].view(-1))
         # weight gradients of the recurrent layers, batched over all clips: ONE launch (+ one reduce)
         self._gg((1, 0, w["dGI0"], 768, w["X"], 64, G[ev + "weight_ih_l0"], 64, 768, 64, R),

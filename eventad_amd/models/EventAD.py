@@ -220,7 +220,7 @@ class EventADModel(nn.Module):
             object.__setattr__(self, "_nh", nh)
         return nh
 
-    def _head_native(self, feats, data, labels):
+    def _head_native(self, feats, data, labels, lean=False):
         from ..head_native import PARAMS
         nh = self.native_head()
         B = int(data.num_graphs)
@@ -229,6 +229,8 @@ class EventADModel(nn.Module):
         if torch.is_grad_enabled():
             params = dict(self.named_parameters())
             return _NativeHeadFn.apply(nh, feats, bbox, bb, labels, B, W, H, self.training, *[params[n] for n, _ in PARAMS])
+        if lean:                                               # TrainStep: results stay in the head's static buffers
+            return nh.forward(feats, bbox, bb, labels, B, W, H, self.training, lean=True)
         loss, logits, valid, targets = nh.forward(feats, bbox, bb, labels, B, W, H, self.training)
         return loss.clone(), logits, valid, targets
 
@@ -246,8 +248,8 @@ class EventADModel(nn.Module):
                 all_labels.append([targets[b, k].unsqueeze(0) for k in ks])
         return losses, all_outputs, all_labels
 
-    def loss_only(self, data, labels):
+    def loss_only(self, data, labels, lean=False):
         """Sync-free training path: features of the current frame only (the previous-frame features are
         computed by the reference but never read by forward, EventAD.py:216)."""
         feats = self.extract_features(data, frames=(1,))
-        return self._head_native(feats, data, labels)
+        return self._head_native(feats, data, labels, lean=lean)

@@ -85,7 +85,7 @@ class TrainStep:
             labels = data.bbox[:, 4]
         if self.native:
             with torch.no_grad():
-                loss, logits, valid, targets = self.model.loss_only(data, labels)
+                loss, logits, valid, targets = self.model.loss_only(data, labels, lean=True)
                 self.nh.backward()
                 if self.world > 1:
                     dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
@@ -164,7 +164,7 @@ class TrainStep:
             with torch.cuda.stream(sg):
                 feats_next = self.model.extract_features(data_next, frames=(1,))
             with torch.cuda.stream(sh):
-                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data_cur, labels_cur)
+                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data_cur, labels_cur, lean=True)
                 self.nh.backward()
                 if self.world > 1:
                     dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
@@ -198,7 +198,7 @@ class TrainStep:
             with torch.cuda.graph(self._gb, capture_error_mode="thread_local"):
                 self._feats_next = self.model.extract_features(data_next, frames=(1,))
             with torch.cuda.graph(self._gh, capture_error_mode="thread_local"):
-                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data, labels)
+                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data, labels, lean=True)
                 self.nh.backward()
                 if self.world > 1:
                     dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
@@ -263,7 +263,7 @@ class TrainStep:
                 out4 = net.tail(hands[1])[0][1]
                 feats_next = self.model.roi_features(out4, data_mid, frames=(1,))
             with torch.cuda.stream(sh):
-                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data_cur, labels_cur)
+                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data_cur, labels_cur, lean=True)
                 self.nh.backward()
                 if self.world > 1:
                     dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
