@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
 # C-ABI call -> kernel name in the rocprofv3 traces / profiles/*_hbm_traffic.json
-KERNEL_OF = {"eventad_build_ell#1": "k_build_ell_reg<true>", "eventad_l1_conv1#1": "k_l1_conv<20, false, true>",
+KERNEL_OF = {"eventad_build_ell#1": "k_build_ell_rowscan<3, true>", "eventad_l1_conv1#1": "k_l1_conv<20, false, true>",
              "eventad_l1_conv2#1": "k_l1_conv<16, true, true>", "eventad_pool_seg0#1": "k_pool_seg0"}
 
 

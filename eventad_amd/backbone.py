@@ -42,7 +42,10 @@ class NativeBackbone:
         self._ws_key = None
         # edge-search kernel: -1 = thread per event, ELL row in registers (fastest on C2: 130 us); >0 = LDS-staged strips of
         # that many pixels (139 us at 64); 0 = batched prefetch (175 us).  All bit-identical (tools/microbench_ell.py).
-        self.strip_width = int(os.environ.get("EVENTAD_ELL_VARIANT", "-1"))   # edge-search kernel, see eventad_build_ell
+        # edge-search kernel (see eventad_build_ell); None = by expected window occupancy: the row-scan kernel (-6) for
+        # sparse windows, the register-row spiral walk (-1, early exit after 16 neighbours) for dense ones
+        v = os.environ.get("EVENTAD_ELL_VARIANT")
+        self.strip_width = int(v) if v else None
         self.fused_mark = True         # pool1 edge bitmap filled by the edge search itself: 172 us vs 134 + 98 us separate (C2)
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
@@ -96,7 +99,7 @@ class NativeBackbone:
             front_arena=front_arena, counters=front_arena[:4], pix_count=front_arena[4:4 + P + 1],
             bitmap0=front_arena[4 + P + 1:].view(S0_, 3),
             key=i32(N), tq=i32(N), bev=i32(N), pix_start=i32(P + 1),
-            scan_tmp=i32(max(P, 1 << 16) // 2048 + 4), sid_tmp=i32(N), sid=i32(N), long_list=i32(P),
+            scan_tmp=i32(2 * (max(P, 1 << 16) // 2048 + 4)), sid_tmp=i32(N), sid=i32(N), long_list=i32(P),
             key_s=i32(N), ts_s=i32(N), ev2=i32(N, 2), posn_s=f32(N, 3), x0s=f32(N, 20),
             ell_src=i32(N, K), ell_step=torch.empty((N, K), dtype=torch.int16, device=dev), deg=i32(N),
             y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N), node_vox0=i32(N), ovf_list=i32(max(N, 1)),
@@ -234,11 +237,15 @@ class NativeBackbone:
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
              ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), 3 * L0_.S, st)     # also clears counters, histogram, pool1 bitmap
-        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if (self.fused_mark or self.strip_width) else None,
+        sw = self.strip_width
+        if sw is None:
+            window = (2 * g.radius_px + 1) ** 2 * N / max(B * g.W * g.H, 1)         # mean events per search window
+            sw = -6 if (g.radius_px in (1, 3) and window < 64) else -1
+        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if (self.fused_mark or sw) else None,
              ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],
-             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, self.strip_width, 1, st)
+             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, sw, 1, st)
         self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
              ptr(w["root1"]), ptr(w["bn1"][0]), ptr(w["bn1"][1]), ptr(ws["y1"]), N, g.steps, K, st)
         self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),

@@ -54,3 +54,47 @@ __device__ __forceinline__ void evad_mark_edge_packed(int vs, int vd, int slot_d
     unsigned m = 1u << (bit & 31);
     if (!(*(volatile unsigned*)w & m)) atomicOr(w, m);
 }
+
+// The same for the <= 15 edges of one ELL row at once: all bitmap words are fetched first (independent loads -- the
+// volatile test-then-set above serialises one round trip per edge), then only the missing bits are OR-ed in.
+// A stale read costs at most a redundant atomicOr.
+template <int MAXNB>
+__device__ __forceinline__ void evad_mark_row_packed(const int (&vs)[MAXNB], int nn, int vd, int slot_d, unsigned* __restrict__ bitmap,
+                                                     unsigned* flags) {
+    unsigned* w[MAXNB]; unsigned m[MAXNB], cur[MAXNB];
+    bool bad = false;
+#pragma unroll
+    for (int e = 1; e < MAXNB; ++e) {
+        w[e] = nullptr; m[e] = 0; cur[e] = 0;
+        if (e < nn && vs[e] != vd) {
+            int dx = (vs[e] & 255) - (vd & 255), dy = ((vs[e] >> 8) & 255) - ((vd >> 8) & 255), dp = (vs[e] >> 16) - (vd >> 16);
+            if (dx < -2 || dx > 2 || dy < -2 || dy > 2 || dp < -1 || dp > 1) bad = true;
+            else {
+                int bit = ((dp + 1) * 5 + (dy + 2)) * 5 + (dx + 2);
+                w[e] = bitmap + (size_t)slot_d * 3 + (bit >> 5); m[e] = 1u << (bit & 31);
+                cur[e] = __builtin_nontemporal_load(w[e]);
+            }
+        }
+    }
+    if (bad) atomicOr(flags, EVAD_FLAG_POOL_WINDOW);
+    unsigned set0 = 0, set1 = 0, set2 = 0;                   // several edges usually hit the same bit: OR each word once
+    unsigned* base = bitmap + (size_t)slot_d * 3;
+#pragma unroll
+    for (int e = 1; e < MAXNB; ++e) if (w[e] && !(cur[e] & m[e])) { int wi = (int)(w[e] - base); if (wi == 0) set0 |= m[e]; else if (wi == 1) set1 |= m[e]; else set2 |= m[e]; }
+    // events are pixel-sorted, so the lanes of a wave fall into a few runs with the same destination voxel: OR the
+    // masks down each run and let its first lane issue the atomics (3 words per run instead of per lane).
+    // Must be reached by every lane of the wave (callers pass nn = 0 for idle lanes).
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int os = __shfl_down(slot_d, d, 64);
+        const unsigned o0 = __shfl_down(set0, d, 64), o1 = __shfl_down(set1, d, 64), o2 = __shfl_down(set2, d, 64);
+        if (lane + d < 64 && os == slot_d) { set0 |= o0; set1 |= o1; set2 |= o2; }
+    }
+    const int prev = __shfl_up(slot_d, 1, 64);
+    if (lane == 0 || prev != slot_d) {
+        if (set0) atomicOr(base, set0);
+        if (set1) atomicOr(base + 1, set1);
+        if (set2) atomicOr(base + 2, set2);
+    }
+}

@@ -182,20 +182,41 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* t
     return base + inc - v;
 }
 
+// tile_max (nullable): also the largest input of each tile (reduced to one number by k_scan_sums)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const unsigned* __restrict__ in, unsigned* __restrict__ out,
-                                                             unsigned* __restrict__ tile_sums, long long n) {
+                                                             unsigned* __restrict__ tile_sums, long long n,
+                                                             unsigned* __restrict__ tile_max) {
+    __shared__ unsigned s_max;
     long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-    unsigned v[SCAN_ITEMS], s = 0;
+    unsigned v[SCAN_ITEMS], s = 0, m = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; s += v[k]; }
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; s += v[k]; m = max(m, v[k]); }
+    if (tile_max) {
+        if (threadIdx.x == 0) s_max = 0;
+        __syncthreads();
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_max, m);
+    }
     unsigned tot, ex = block_exclusive_scan(s, &tot);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+    if (threadIdx.x == 0) { tile_sums[blockIdx.x] = tot; if (tile_max) tile_max[blockIdx.x] = s_max; }
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(unsigned* __restrict__ tile_sums, int n_tiles,
-                                                            unsigned* __restrict__ grand_total) {
+                                                            unsigned* __restrict__ grand_total,
+                                                            const unsigned* __restrict__ tile_max, unsigned* __restrict__ max_out) {
+    if (tile_max) {
+        __shared__ unsigned s_max;
+        if (threadIdx.x == 0) s_max = 0;
+        __syncthreads();
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < n_tiles; i += SCAN_THREADS) m = max(m, tile_max[i]);
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_max, m);
+        __syncthreads();
+        if (threadIdx.x == 0) *max_out = s_max;
+    }
     unsigned carry = 0;
     for (int base = 0; base < n_tiles; base += SCAN_THREADS) {
         int i = base + threadIdx.x;
@@ -213,13 +234,19 @@ __global__ void k_scan_add(unsigned* __restrict__ out, const unsigned* __restric
 }
 
 // out has n+1 entries (out[n] = grand total); tile_sums needs ceil(n/2048) entries.  in may alias out.
-int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, hipStream_t st) {
+// max_out (nullable): also max(in); tile_sums then needs 2*ceil(n/2048) entries.
+int evad_exclusive_scan_max(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, unsigned* max_out, hipStream_t st) {
     if (n <= 0) { hipMemsetAsync(out, 0, sizeof(unsigned), st); return evad_last_error(); }
     int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(SCAN_THREADS), 0, st, in, out, tile_sums, n);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, tiles, out + n);
+    unsigned* tile_max = max_out ? tile_sums + tiles : nullptr;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(SCAN_THREADS), 0, st, in, out, tile_sums, n, tile_max);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, tiles, out + n, tile_max, max_out);
     if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(evad_blocks(n, 256)), dim3(256), 0, st, out, tile_sums, n);
     return evad_last_error();
+}
+
+int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, hipStream_t st) {
+    return evad_exclusive_scan_max(in, out, tile_sums, n, nullptr, st);
 }
 
 extern "C" int eventad_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, int64_t n, void* stream) {
@@ -235,7 +262,7 @@ __device__ __forceinline__ int denorm(float p, float scale) { return (int)__fadd
 
 __global__ void k_prep_events(const float* __restrict__ pos, const long long* __restrict__ batch, int N, int B, int W,
                               int H, int T, int* __restrict__ key, int* __restrict__ tq, int* __restrict__ bev,
-                              unsigned* __restrict__ count, unsigned* __restrict__ flags) {
+                              unsigned* __restrict__ count, unsigned* __restrict__ flags, int* __restrict__ arrival) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     float pt = pos[3 * i + 2];
@@ -251,25 +278,16 @@ __global__ void k_prep_events(const float* __restrict__ pos, const long long* __
     if (f) atomicOr(flags, f);
     int k = x + W * (y + H * b);
     key[i] = k; tq[i] = t; bev[i] = b;
-    atomicAdd(&count[k], 1u);
+    arrival[i] = (int)atomicAdd(&count[k], 1u);          // arrival order inside the pixel: the scatter needs no second atomic
 }
 
 __global__ void k_scatter_events(const int* __restrict__ key, const unsigned* __restrict__ start,
-                                 unsigned* __restrict__ count, int* __restrict__ sid_tmp, int N, unsigned* __restrict__ lmax) {
+                                 const int* __restrict__ arrival, int* __restrict__ sid_tmp, int N) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) { return; }
-    int k = key[i];
-    unsigned c = atomicSub(&count[k], 1u);               // old value: 1..cnt
-    sid_tmp[start[k] + c - 1] = i;
-    // longest pixel segment of the batch (bounds the binary searches of k_build_ell_bf): one atomic per wave
-    unsigned m = c;
-    for (int d = 32; d > 0; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
-    if ((threadIdx.x & 63) == 0 && m > *(volatile unsigned*)lmax) atomicMax(lmax, m);   // a same-address atomic per wave costs 60 us
+    if (i >= N) return;
+    sid_tmp[start[key[i]] + arrival[i]] = i;             // unordered inside the segment; k_gather_sorted ranks by id
 }
 
-// Order every pixel segment by event id (rank placement; ids are unique).  Short segments are
-// done by one thread; long ones are queued for the wave-cooperative kernel below.
-#define SEG_SHORT 32
 // Sorted-order event records + the 19(+1)-channel layer-1 input row
 //   x0s[r] = [polarity, 16 bilinear samples of CNN map 0, pos_x, pos_y, 0]   (reference net.py:116,122-123)
 // The sampler restates F.grid_sample(align_corners=True, zeros padding) as called by
@@ -384,11 +402,11 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     if (node_slot && (!px_to_cx || !py_to_cy || !ovf_list || !node_vox || nx <= 0 || ny <= 0 || vsx <= 0 || vsy <= 0)) return EVAD_ERR_ARG;
     if (N > 0)
         hipLaunchKernelGGL(k_prep_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, pos, (const long long*)batch, N, B,
-                           W, H, T, key, tq, bev, pix_count, counters);
-    int rc = evad_exclusive_scan(pix_count, pix_start, scan_tmp, P, st);
+                           W, H, T, key, tq, bev, pix_count, counters, sid);      // sid doubles as the arrival-rank scratch
+    int rc = evad_exclusive_scan_max(pix_count, pix_start, scan_tmp, P, counters + 3, st);   // [3] = longest pixel segment
     if (rc) return rc;
     if (N == 0) return evad_last_error();
-    hipLaunchKernelGGL(k_scatter_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, pix_count, sid_tmp, N, counters + 3);
+    hipLaunchKernelGGL(k_scatter_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, sid, sid_tmp, N);
     hipLaunchKernelGGL(k_gather_sorted, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid_tmp, pix_start, sid, key, tq, pos, polarity,
                        map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, (int2*)ev2, posn_s, x0s, vsx, vsy, nx, ny, nx * ny * (B + 1),
                        px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, counters);
@@ -1117,6 +1135,159 @@ static bool tile_plan(int B, int W, int H, int rad, int* R, int* TBL, int* CAP, 
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-scan edge search for sparse windows (mean events per (2R+1)^2 window well below 64; R = 1 or 3).
+// The 49 probes of a 7x7 window cost ~245 lane-instructions each in the kernels above, mostly address
+// arithmetic and divergence on (half-)empty pixels.  But the pixels x-R..x+R of one sensor row are ONE
+// contiguous range of the pixel-sorted event array, so a destination needs 2R+1 range look-ups, not (2R+1)^2:
+// every lane scans the events of its 2R+1 row ranges (all lanes converged; trip count = the longest range of the
+// wave), tests each candidate exactly as the reference does (older id, dt <= delta_t), and appends the
+// survivors as (spiral step << 12 | 4095 - offset in the row range) keys to a per-lane LDS list.  The <= 15
+// smallest keys in ascending order ARE the reference's edges in its order (spiral step, newest first within a
+// pixel).  Lanes with more than RS_CAP survivors, batches with a pixel deeper than the FIFO (the depth cap
+// then matters) or ranges longer than 4096 take the exact per-lane spiral walk instead.
+#define RS_CAP 32
+#define RS_UNR 8
+template <int MAXNB>
+__device__ __forceinline__ int ell_exact_walk(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int me, int ts,
+                                              int x, int y, int plane_base, int W, int H, int steps, int Q, int dt_max,
+                                              bool monotone, int (&nb)[MAXNB], int (&stp)[MAXNB]) {
+    int nn = 1;
+    for (int i = 0; i < steps && nn < MAXNB; ++i) {
+        int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+        if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
+        int p = plane_base + xn + W * yn;
+        int st = (int)start[p], en = (int)start[p + 1];
+        int lo = max(st, en - Q);
+        for (int s = en - 1; s >= lo; --s) {
+            const int2 c = ev2[s];
+            if (me > c.x) {
+                if ((float)(ts - c.y) > (float)dt_max) { if (monotone) break; else continue; }
+#pragma unroll
+                for (int e = 1; e < MAXNB; ++e) if (e == nn) { nb[e] = s; stp[e] = i; }
+                if (++nn >= MAXNB) break;
+            }
+        }
+    }
+    return nn;
+}
+
+template <int R, bool MARK>
+__global__ __launch_bounds__(256) void k_build_ell_rowscan(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+                                                           const unsigned* __restrict__ start, const unsigned* flags_in, int N,
+                                                           int W, int H, int steps, int Q, int dt_max, int* __restrict__ ell_src,
+                                                           uint16_t* __restrict__ ell_step, int* __restrict__ deg,
+                                                           const int* __restrict__ node_slot, const int* __restrict__ node_vox,
+                                                           unsigned* __restrict__ bitmap, unsigned* flags) {
+    constexpr int MAXNB = 16, D = 2 * R + 1;
+    __shared__ unsigned s_key[256][RS_CAP + 1];
+    __shared__ unsigned short s_stepof[D * D];
+    __shared__ signed char s_dyi[D * D];
+    const int tid = threadIdx.x;
+    if (tid < D * D) { s_stepof[tid] = (unsigned short)c_stepof[tid]; s_dyi[tid] = (signed char)(c_spiral[2 * tid + 1] + R); }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + tid;
+    const bool active = r < N;
+    const bool monotone = !(flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE);
+    const int lmax = (int)flags_in[3];
+    int me = 0, ts = 0, x = 0, y = 0, plane_base = 0;
+    if (active) {
+        const int k = key_s[r];
+        const int2 mine = ev2[r];
+        me = mine.x; ts = mine.y; x = k % W; y = (k / W) % H; plane_base = k - x - W * y;
+    }
+    int nb[MAXNB], stp[MAXNB];
+#pragma unroll
+    for (int e = 0; e < MAXNB; ++e) { nb[e] = 0; stp[e] = 0; }
+    nb[0] = r;
+    int nn = 1;
+    bool exact = lmax > Q || lmax * D > 4096;                // uniform: depth cap binding / offsets beyond 12 bits
+    if (!exact) {
+        int ra[D], rbv[D], n = 0;
+        const int xlo = max(x - R, 0), xhi = min(x + R, W - 1);
+#pragma unroll
+        for (int dyi = 0; dyi < D; ++dyi) {                  // all 2(2R+1) range bounds in flight at once
+            const int yn = y + dyi - R;
+            ra[dyi] = 0; rbv[dyi] = 0;
+            if (active && yn >= 0 && yn < H) {
+                const int rowbase = plane_base + W * yn;
+                ra[dyi] = (int)start[rowbase + xlo]; rbv[dyi] = (int)start[rowbase + xhi + 1];
+            }
+        }
+#pragma unroll
+        for (int dyi = 0; dyi < D; ++dyi) {
+            const int len = rbv[dyi] - ra[dyi];
+            int maxlen = len;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d, 64));
+            const int xbase = plane_base + W * (y + dyi - R) + x - R;   // key of the window's left-most pixel in this row
+            for (int j0 = 0; j0 < maxlen; j0 += RS_UNR) {    // RS_UNR candidates (2 RS_UNR independent loads) per round trip
+                int2 ce[RS_UNR]; int kc[RS_UNR];
+#pragma unroll
+                for (int u = 0; u < RS_UNR; ++u) {
+                    ce[u] = make_int2(0x7fffffff, 0); kc[u] = 0;
+                    if (j0 + u < len) { ce[u] = ev2[ra[dyi] + j0 + u]; kc[u] = key_s[ra[dyi] + j0 + u]; }
+                }
+#pragma unroll
+                for (int u = 0; u < RS_UNR; ++u) {
+                    if (me > ce[u].x && !((float)(ts - ce[u].y) > (float)dt_max)) {
+                        const int dxi = kc[u] - xbase;                       // 0..2R
+                        const unsigned key = ((unsigned)s_stepof[dyi * D + dxi] << 12 | (unsigned)(4095 - (j0 + u))) + 1u;
+                        if (n < RS_CAP) s_key[tid][n] = key;
+                        ++n;
+                    }
+                }
+            }
+        }
+        if (n > RS_CAP) exact = true;                        // this lane only
+        else {
+            int maxn = n;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) maxn = max(maxn, __shfl_xor(maxn, d, 64));
+            unsigned last = 0;
+#pragma unroll
+            for (int e = 1; e < MAXNB; ++e) {
+                unsigned best = 0xffffffffu;
+                if (e <= n) {
+                    for (int i0 = 0; i0 < maxn; i0 += 4) {               // 4 independent LDS reads per step
+                        unsigned kk[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) kk[u] = i0 + u < n ? s_key[tid][i0 + u] : 0xffffffffu;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (kk[u] > last && kk[u] < best) best = kk[u];
+                    }
+                    last = best;
+                    const unsigned q = best - 1u;
+                    const int step = (int)(q >> 12), j = 4095 - (int)(q & 4095u), dyi = s_dyi[step];
+                    int base = ra[0];
+#pragma unroll
+                    for (int t = 1; t < D; ++t) if (t == dyi) base = ra[t];
+                    nb[e] = base + j; stp[e] = step;
+                }
+            }
+            nn = 1 + min(n, MAXNB - 1);
+        }
+    }
+    if (exact && active) nn = ell_exact_walk<MAXNB>(ev2, start, me, ts, x, y, plane_base, W, H, steps, Q, dt_max, monotone, nb, stp);
+    if (active) {
+        int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
+        rp[0] = make_int4(nb[0], nb[1], nb[2], nb[3]); rp[1] = make_int4(nb[4], nb[5], nb[6], nb[7]);
+        rp[2] = make_int4(nb[8], nb[9], nb[10], nb[11]); rp[3] = make_int4(nb[12], nb[13], nb[14], nb[15]);
+        uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
+        sp4[0] = make_uint4(stp[0] | stp[1] << 16, stp[2] | stp[3] << 16, stp[4] | stp[5] << 16, stp[6] | stp[7] << 16);
+        sp4[1] = make_uint4(stp[8] | stp[9] << 16, stp[10] | stp[11] << 16, stp[12] | stp[13] << 16, stp[14] | stp[15] << 16);
+        deg[r] = nn;
+    }
+    if (MARK) {                                              // every lane takes part in the wave-level combine
+        const int my_slot = active ? node_slot[r] : -1, my_vox = active ? node_vox[r] : 0;
+        if (!active) nn = 0;
+        int vs[MAXNB];
+#pragma unroll
+        for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[nb[e]] : my_vox;
+        evad_mark_row_packed<MAXNB>(vs, nn, my_vox, my_slot, bitmap, flags);
+    }
+}
+
 extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                                  const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
@@ -1133,6 +1304,15 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
     if (ensure_spiral(radius_px, st, &steps)) return -2;
     if (steps > 65535) return EVAD_ERR_ARG;
     int tR = 0, tTBL = 0, tCAP = 0; size_t tlds = 0;
+    if (max_num_neighbors == 16 && ev2 && strip_width == -6 && (radius_px == 1 || radius_px == 3)) {
+        dim3 grid(evad_blocks(N, 256));
+#define EVAD_RS(RR, MK) hipLaunchKernelGGL((k_build_ell_rowscan<RR, MK>), grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, \
+                                            N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters)
+        if (radius_px == 1) { if (bitmap) EVAD_RS(1, true); else EVAD_RS(1, false); }
+        else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
+#undef EVAD_RS
+        return evad_last_error();
+    }
     if (max_num_neighbors == 16 && ev2 && strip_width == -5 && radius_px <= SPIRAL_MAX_R && tile_plan(B, W, H, radius_px, &tR, &tTBL, &tCAP, &tlds)) {
         dim3 grid((unsigned)(B * ((H + tR - 1) / tR)));
         if (bitmap) hipLaunchKernelGGL(k_build_ell_tile<true>, grid, dim3(256), tlds, st, (const int2*)ev2, key_s, pix_start, counters, W, H, tR,

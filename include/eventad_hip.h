@@ -54,7 +54,7 @@ int eventad_spiral_offsets(int radius, int16_t* dxdy);
  *   in : pos f32[N,3] normalised, batch i64[N], polarity f32[N], map0 f32[B,h,w,16] (NHWC)
  *   out: key/tq/bev i32[N] (event order: pixel key, t in us, clip), pix_start u32[B*H*W+1],
  *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], ev2 i32[N,2] = {id, t} pairs (nullable), posn_s f32[N,3], x0s f32[N,20]
- *   ws : pix_count u32[B*H*W+1], scan_tmp u32[B*H*W/2048+2], sid_tmp i32[N], long_list (reserved, unused),
+ *   ws : pix_count u32[B*H*W+1], scan_tmp u32[2*(B*H*W/2048+2)], sid_tmp i32[N], long_list (reserved, unused),
  *        counters u32[4], zeroed by this call -- the first of a step ([0] = EVENTAD_FLAG_* bits, accumulated by the
  *        later stages; [1] unused; [2] = length of ovf_list; [3] = longest pixel segment of the batch).
  *        When pix_count == counters + 4 the two are cleared by ONE memset, which then also covers the
@@ -77,7 +77,8 @@ int eventad_sort_events(const float* pos, const int64_t* batch, const float* pol
  * strip_width (needs ev2): > 0 LDS-staged search, one wave per strip of that many pixels of a sensor row;
  * 0 batched prefetch; -1 thread per event, row in registers (default); -2 row-parallel; -3 wave per event with
  * binary-searched ranges; -4 converged lanes with fixed-trip binary searches; -5 the same over LDS-staged row
- * strips.  All variants give identical rows.  bitmap_prezeroed != 0: the caller already cleared the bitmap. */
+ * strips; -6 row scan (radius 1 or 3; 2R+1 contiguous range look-ups per event instead of (2R+1)^2 pixel probes, the
+ * fastest for sparse windows).  All variants give identical rows.  bitmap_prezeroed != 0: the caller already cleared the bitmap. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                       int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step, int32_t* deg,

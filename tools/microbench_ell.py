@@ -56,6 +56,10 @@ t = timeit(lambda: ell(None, -4))
 ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
 print("build_ell converged lanes: %.1f us  (matches %s)  lmax %d" % (t, ok, int(ws["counters"][3])))
 print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -4)))
+t = timeit(lambda: ell(None, -6))
+ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
+print("build_ell row scan       : %.1f us  (matches %s)" % (t, ok))
+print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -6)))
 t = timeit(lambda: ell(None, -5))
 ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
 print("build_ell LDS row tiles  : %.1f us  (matches %s)" % (t, ok))
