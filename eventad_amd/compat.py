@@ -77,7 +77,17 @@ def _ev_graph_module():
     return m
 
 
-def install():
+# the test/validation loop: only these two modules of the reference's `utils` package are replaced --
+# the package itself (data loaders, result files, ...) stays the reference's, so they are registered as submodules
+_EVAL_ALIASES = {"utils.test": "eventad_amd.utils.test", "utils.evaluation": "eventad_amd.utils.evaluation"}
+
+
+def install(eval_loop=False):
+    """eval_loop=True additionally routes `utils.test.collect_predictions` and `utils.evaluation.*` (test.py:8-9) to
+    the sync-free versions in eventad_amd/utils/."""
     for alias, target in _ALIASES.items():
         sys.modules[alias] = importlib.import_module(target)
     sys.modules["ev_graph_cuda"] = _ev_graph_module()
+    if eval_loop:
+        for alias, target in _EVAL_ALIASES.items():
+            sys.modules[alias] = importlib.import_module(target)

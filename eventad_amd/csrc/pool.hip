@@ -264,16 +264,17 @@ int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, 
 
 // occupancy flags + exclusive scan in ONE single-workgroup launch (S <= ~100k slots: 4 launches -> 1)
 __global__ __launch_bounds__(1024) void k_occ_scan_small(const unsigned* __restrict__ cnt, unsigned* __restrict__ out, int S) {
+    constexpr int IT = 16;                                   // items per thread per pass: 16K slots per pass, loads in flight together
     __shared__ unsigned wsum[16];
     __shared__ unsigned carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < S; base += 1024 * 4) {
-        unsigned v[4], s = 0;
-        int i0 = base + tid * 4;
+    for (int base = 0; base < S; base += 1024 * IT) {
+        unsigned v[IT], s = 0;
+        int i0 = base + tid * IT;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < S && cnt[i0 + k] > 0) ? 1u : 0u; s += v[k]; }
+        for (int k = 0; k < IT; ++k) { v[k] = (i0 + k < S && cnt[i0 + k] > 0) ? 1u : 0u; s += v[k]; }
         unsigned inc = s;
         for (int d = 1; d < 64; d <<= 1) { unsigned t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
         if (lane == 63) wsum[wv] = inc;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(1024) void k_occ_scan_small(const unsigned* __restr
         for (int w = 0; w < 16; ++w) { if (w < wv) wbase += wsum[w]; tot += wsum[w]; }
         unsigned ex = carry_s + wbase + inc - s;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { if (i0 + k < S) out[i0 + k] = ex; ex += v[k]; }
+        for (int k = 0; k < IT; ++k) { if (i0 + k < S) out[i0 + k] = ex; ex += v[k]; }
         __syncthreads();
         if (tid == 0) carry_s += tot;
         __syncthreads();
@@ -396,23 +397,34 @@ __global__ void k_edge_count(const unsigned* __restrict__ bitmap, const int* __r
 // per-destination edge counts + exclusive scan in one single-workgroup launch (small graphs)
 __global__ __launch_bounds__(1024) void k_edge_count_scan_small(const unsigned* __restrict__ bitmap, const int* __restrict__ node_slot_out,
                                                                 int n_max, const int* __restrict__ n_dev, unsigned* __restrict__ rowptr) {
+    constexpr int IT = 8;                                    // nodes per thread per pass (their slot + 3 bitmap words load together)
     __shared__ unsigned wsum[16];
     __shared__ unsigned carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = min(*n_dev, n_max), total = n_max + 1;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < total; base += 1024) {
-        int j = base + tid;
-        unsigned d = 0;
-        if (j < n) { const unsigned* w = bitmap + (size_t)node_slot_out[j] * 3; d = __popc(w[0]) + __popc(w[1]) + __popc(w[2]); }
-        unsigned inc = d;
+    for (int base = 0; base < total; base += 1024 * IT) {
+        const int j0 = base + tid * IT;
+        unsigned d[IT], s = 0;
+        int sl[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) sl[k] = j0 + k < n ? node_slot_out[j0 + k] : -1;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            d[k] = 0;
+            if (sl[k] >= 0) { const unsigned* w = bitmap + (size_t)sl[k] * 3; d[k] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]); }
+            s += d[k];
+        }
+        unsigned inc = s;
         for (int dd = 1; dd < 64; dd <<= 1) { unsigned t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
         if (lane == 63) wsum[wv] = inc;
         __syncthreads();
         unsigned wbase = 0, tot = 0;
         for (int w = 0; w < 16; ++w) { if (w < wv) wbase += wsum[w]; tot += wsum[w]; }
-        if (j < total) rowptr[j] = carry_s + wbase + inc - d;
+        unsigned ex = carry_s + wbase + inc - s;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { if (j0 + k < total) rowptr[j0 + k] = ex; ex += d[k]; }
         __syncthreads();
         if (tid == 0) carry_s += tot;
         __syncthreads();

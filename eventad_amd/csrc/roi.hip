@@ -11,6 +11,9 @@
 
 #define ROI_MAX_BOXES 30
 
+// One wave per box row.  Node tests run 64 nodes at a time (lane = node); everything whose floating-point result
+// depends on order -- the weight sum, the 5-nearest insertion, the weighted feature sum -- is then replayed in
+// ascending node order from ballot masks, so the results are those of the sequential loops of the reference.
 __global__ __launch_bounds__(64) void k_roi_pool(const float* __restrict__ nx, const float* __restrict__ npos,
                                                  const int* __restrict__ nbatch, const int* __restrict__ n_dev, int n_max,
                                                  const float* __restrict__ bbox, const long long* __restrict__ bbox_batch,
@@ -23,8 +26,11 @@ __global__ __launch_bounds__(64) void k_roi_pool(const float* __restrict__ nx, c
     const int track = (int)bb[5];
     if (track <= 0 || track > ROI_MAX_BOXES || b < 0 || b >= B) return;
     // the reference processes rows in order and overwrites: the LAST row of (clip, track) wins
-    for (int m2 = m + 1; m2 < M; ++m2)
-        if ((int)bbox_batch[m2] == b && (int)bbox[(size_t)m2 * 6 + 5] == track) return;
+    for (int base = m + 1; base < M; base += 64) {
+        const int m2 = base + c;
+        const bool later = m2 < M && (int)bbox_batch[m2] == b && (int)bbox[(size_t)m2 * 6 + 5] == track;
+        if (__ballot(later)) return;
+    }
     const double x = bb[0], y = bb[1], w = bb[2], h = bb[3];
     const double x1d = x / (double)Wimg, y1d = y / (double)Himg, x2d = (x + w) / (double)Wimg, y2d = (y + h) / (double)Himg;
     const float x1 = (float)x1d, y1 = (float)y1d, x2 = (float)x2d, y2 = (float)y2d;
@@ -36,30 +42,47 @@ __global__ __launch_bounds__(64) void k_roi_pool(const float* __restrict__ nx, c
     float bd[5]; int bi[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) { bd[k] = 3.4e38f; bi[k] = -1; }
-    for (int i = 0; i < n; ++i) {
-        if (nbatch[i] != b) continue;
-        ++n_clip;
-        float px = npos[3 * i], py = npos[3 * i + 1];
-        float dx = px - cx, dy = py - cy;
-        float d = sqrtf(dx * dx + dy * dy);
-        if (px >= x1 && px <= x2 && py >= y1 && py <= y2) { ++n_in; wsum += 1.0f / (d + 1e-6f); }
-        if (d < bd[4]) {                                         // insertion into the 5 smallest (stable in index)
-            int k = 4;
-            while (k > 0 && d < bd[k - 1]) { bd[k] = bd[k - 1]; bi[k] = bi[k - 1]; --k; }
-            bd[k] = d; bi[k] = i;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + c;
+        const bool mine = i < n && nbatch[i] == b;
+        float px = 0.f, py = 0.f;
+        if (mine) { px = npos[3 * i]; py = npos[3 * i + 1]; }
+        const float dx = px - cx, dy = py - cy;
+        const float d = sqrtf(dx * dx + dy * dy);
+        const bool in = mine && px >= x1 && px <= x2 && py >= y1 && py <= y2;
+        const float wl = 1.0f / (d + 1e-6f);
+        const unsigned long long mclip = __ballot(mine);
+        unsigned long long min_ = __ballot(in);
+        n_clip += __popcll(mclip); n_in += __popcll(min_);
+        while (min_) { const int l = __ffsll((long long)min_) - 1; min_ &= min_ - 1; wsum += __shfl(wl, l, 64); }
+        unsigned long long mc = __ballot(mine && d < bd[4]);         // candidates of the 5 smallest (stable in index)
+        while (mc) {
+            const int l = __ffsll((long long)mc) - 1; mc &= mc - 1;
+            const float cd = __shfl(d, l, 64);
+            if (cd < bd[4]) {
+                int k = 4;
+                while (k > 0 && cd < bd[k - 1]) { bd[k] = bd[k - 1]; bi[k] = bi[k - 1]; --k; }
+                bd[k] = cd; bi[k] = base + l;
+            }
         }
     }
     float* o = feats + (((size_t)b * n_frames + frame) * (ROI_MAX_BOXES + 1) + track) * 64;
     if (n_clip == 0) { o[c] = 0.f; return; }                     // global feature of an empty clip = zeros
     float acc = 0.f;
     if (n_in > 0) {
-        for (int i = 0; i < n; ++i) {
-            if (nbatch[i] != b) continue;
-            float px = npos[3 * i], py = npos[3 * i + 1];
-            if (!(px >= x1 && px <= x2 && py >= y1 && py <= y2)) continue;
-            float dx = px - cx, dy = py - cy;
-            float wgt = (1.0f / (sqrtf(dx * dx + dy * dy) + 1e-6f)) / wsum;
-            acc += nx[(size_t)i * 64 + c] * wgt;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + c;
+            const bool mine = i < n && nbatch[i] == b;
+            float px = 0.f, py = 0.f;
+            if (mine) { px = npos[3 * i]; py = npos[3 * i + 1]; }
+            const bool in = mine && px >= x1 && px <= x2 && py >= y1 && py <= y2;
+            const float dx = px - cx, dy = py - cy;
+            const float wgt = (1.0f / (sqrtf(dx * dx + dy * dy) + 1e-6f)) / wsum;
+            unsigned long long min_ = __ballot(in);
+            while (min_) {
+                const int l = __ffsll((long long)min_) - 1; min_ &= min_ - 1;
+                acc += nx[(size_t)(base + l) * 64 + c] * __shfl(wgt, l, 64);
+            }
         }
     } else {
         int k = min(5, n_clip);

@@ -248,6 +248,15 @@ class EventADModel(nn.Module):
                 all_labels.append([targets[b, k].unsqueeze(0) for k in ks])
         return losses, all_outputs, all_labels
 
+    @torch.no_grad()
+    def predict_tensors(self, data, labels=None):
+        """Device-side result of forward(): (logits f32[B,31,2], valid bool[B,31], targets i64[B,31]) -- the padded
+        tables behind the nested lists, for consumers that want ONE host transfer per batch
+        (eventad_amd/utils/test.py::collect_predictions)."""
+        feats = self.extract_features(data, frames=(0, 1))
+        loss, logits, valid, targets = self._head_native(feats, data, labels)
+        return logits[:, :T], valid[:, :T], targets[:, :T]
+
     def loss_only(self, data, labels, lean=False):
         """Sync-free training path: features of the current frame only (the previous-frame features are
         computed by the reference but never read by forward, EventAD.py:216)."""
