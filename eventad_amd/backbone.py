@@ -258,16 +258,23 @@ class NativeBackbone:
                 ptr(ws["key_s"]), ptr(ws["sid"]), ptr(ws["node_slot0"]), ptr(ws["pix_start"]), ptr(self.vox_tabs[2]),
                 ptr(self.vox_tabs[3]), ptr(ws["ovf_list"]), ptr(ws["counters"]), N, B, g.W, g.H, L.nx, L.ny,
                 ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), st)
-        self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
-             L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
-             ptr(ws["scan_tmp"]), _rp(hand.x), L.ldx, _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot),
-             ptr(L.slot2node), _rp(hand.n_dev), st)
+        small = L.S <= 131072                               # both scans of the level fit the single-workgroup kernel
         if not self.fused_mark:
             self._c("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
                  L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)
-        self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.npix), L.n_max,
-             _rp(hand.n_dev), L.nx, L.ny, _rp(hand.rowptr), ptr(ws["scan_tmp"]), _rp(hand.csr_src), _rp(hand.csr_dxy),
-             _rp(hand.e_dev), st)
+        if small:
+            self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
+                 ptr(L.bitmap), L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ), _rp(hand.x), L.ldx,
+                 _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.n_dev),
+                 _rp(hand.rowptr), _rp(hand.csr_src), _rp(hand.csr_dxy), _rp(hand.e_dev), st)
+        else:
+            self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
+                 L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
+                 ptr(ws["scan_tmp"]), _rp(hand.x), L.ldx, _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot),
+                 ptr(L.slot2node), _rp(hand.n_dev), st)
+            self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.npix), L.n_max,
+                 _rp(hand.n_dev), L.nx, L.ny, _rp(hand.rowptr), ptr(ws["scan_tmp"]), _rp(hand.csr_src), _rp(hand.csr_dxy),
+                 _rp(hand.e_dev), st)
         return hand
 
     def tail(self, hand):
@@ -295,15 +302,21 @@ class NativeBackbone:
                      _rp(Lp.npos), _rp(Lp.npix), _rp(Lp.nbatch), None, None, Lp.n_max, _rp(Lp.n_dev), g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
                      ptr(Lp.node_slot_in), ptr(ws["flags_tail"]), 1, st)
-                self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), _rp(Lp.nbatch),
-                     L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
-                     ptr(ws["scan_tmp_tail"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
-                     ptr(L.slot2node), ptr(L.n_dev), st)
                 self._c("eventad_pool_edges_mark_csr", _rp(Lp.rowptr), _rp(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
                      _rp(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["flags_tail"]), 1, st)
-                self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
-                     ptr(L.n_dev), L.nx, L.ny, ptr(L.rowptr), ptr(ws["scan_tmp_tail"]), ptr(L.csr_src), ptr(L.csr_dxy),
-                     ptr(L.e_dev), st)
+                if L.S <= 131072:
+                    self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
+                         _rp(Lp.nbatch), ptr(L.bitmap), L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
+                         ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot), ptr(L.slot2node), ptr(L.n_dev),
+                         ptr(L.rowptr), ptr(L.csr_src), ptr(L.csr_dxy), ptr(L.e_dev), st)
+                else:
+                    self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), _rp(Lp.nbatch),
+                         L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
+                         ptr(ws["scan_tmp_tail"]), ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot),
+                         ptr(L.slot2node), ptr(L.n_dev), st)
+                    self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), ptr(L.npix), L.n_max,
+                         ptr(L.n_dev), L.nx, L.ny, ptr(L.rowptr), ptr(ws["scan_tmp_tail"]), ptr(L.csr_src), ptr(L.csr_dxy),
+                         ptr(L.e_dev), st)
             # Layer lv+2 on this level's graph
             t = self.tail_w[lv]
             dvx, dvy = g.lut_div[lv + 1]

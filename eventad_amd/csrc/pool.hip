@@ -459,6 +459,151 @@ __global__ void k_edge_emit(const unsigned* __restrict__ bitmap, const int* __re
     }
 }
 
+// --------------------------------------------------------------------------- finalize + edges in two launches
+// (the pooled levels hold 20160 / 5040 / 1260 / 315 slots at B = 8 -- every dependent launch costs more
+// than its work.)  Launch 1, one workgroup: BOTH exclusive scans of a level in one pass over the slots --
+// occupancy (= node numbering, slot order) and out-degree popcount(bitmap) of the occupied slots (= CSR row
+// pointers; a set bit always names an occupied neighbour slot).  Launch 2: node attributes, features and the CSR
+// columns together; the pixel of a neighbour node is recomputed from its slot sums by the same function that
+// produces npix, so csr_dxy is bit-identical to the three-launch path.
+__global__ __launch_bounds__(1024) void k_slot_scans_small(const unsigned* __restrict__ cnt, const unsigned* __restrict__ bitmap, int S,
+                                                           int n_max, unsigned* __restrict__ occ_scan, unsigned* __restrict__ rowptr,
+                                                           int* __restrict__ n_out, int* __restrict__ e_out) {
+    constexpr int IT = 8;
+    __shared__ unsigned wsum[16], wsum2[16];
+    __shared__ unsigned carry_n, carry_e;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { carry_n = 0; carry_e = 0; }
+    __syncthreads();
+    for (int base = 0; base < S; base += 1024 * IT) {
+        const int i0 = base + tid * IT;
+        unsigned v[IT], d[IT], sn = 0, se = 0;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) v[k] = (i0 + k < S && cnt[i0 + k] > 0) ? 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            d[k] = 0;
+            if (v[k]) { const unsigned* w = bitmap + (size_t)(i0 + k) * 3; d[k] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]); }
+            sn += v[k]; se += d[k];
+        }
+        unsigned in_ = sn, ie = se;
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            unsigned t = __shfl_up(in_, dd, 64), u = __shfl_up(ie, dd, 64);
+            if (lane >= dd) { in_ += t; ie += u; }
+        }
+        if (lane == 63) { wsum[wv] = in_; wsum2[wv] = ie; }
+        __syncthreads();
+        unsigned bn = 0, be = 0, tn = 0, te = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wv) { bn += wsum[w]; be += wsum2[w]; } tn += wsum[w]; te += wsum2[w]; }
+        unsigned en = carry_n + bn + in_ - sn, ee = carry_e + be + ie - se;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            if (i0 + k < S) occ_scan[i0 + k] = en;
+            if (v[k]) rowptr[en] = ee;
+            en += v[k]; ee += d[k];
+        }
+        __syncthreads();
+        if (tid == 0) { carry_n += tn; carry_e += te; }
+        __syncthreads();
+    }
+    const unsigned n = carry_n, E = carry_e;
+    if (tid == 0) { occ_scan[S] = n; *n_out = (int)n; *e_out = (int)E; }
+    for (int j = (int)n + tid; j <= n_max + 1; j += 1024) rowptr[j] = E;     // rows past the last node are empty
+}
+
+struct SlotPix { int qx, qy; float ox, oy, mt; };
+__device__ __forceinline__ SlotPix slot_pixel(const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ tsum,
+                                              unsigned c, int s, int level0, float Wf, float Hf, float whx, float why, bool want_t) {
+    // pool_pos: mean of the members' normalised positions (level 0: pos = px/W; pooled levels: pos = q * (1/W)), then
+    // round_to_pixel (pooling.py:47-49): floor((p + 1e-5) / wh_inv) * wh_inv.  Same expressions as k_finalize.
+    float sx = (float)sums[2 * (size_t)s], sy = (float)sums[2 * (size_t)s + 1];
+    float fx = level0 ? __fdiv_rn(sx, Wf) : __fmul_rn(sx, whx);
+    float fy = level0 ? __fdiv_rn(sy, Hf) : __fmul_rn(sy, why);
+    float cf = (float)c;
+    float mx = __fdiv_rn(fx, cf), my = __fdiv_rn(fy, cf);
+    SlotPix r;
+    r.mt = want_t ? (float)(((double)tsum[s] / 1099511627776.0) / (double)c) : 0.f;
+    float qx = floorf(__fdiv_rn(__fadd_rn(mx, 1e-5f), whx)), qy = floorf(__fdiv_rn(__fadd_rn(my, 1e-5f), why));
+    r.qx = (int)qx; r.qy = (int)qy; r.ox = __fmul_rn(qx, whx); r.oy = __fmul_rn(qy, why);
+    return r;
+}
+
+template <int MODE>      // 0: ordered-uint max, 1: float sum -> mean, 2: float max
+__global__ void k_finalize_emit(const unsigned* __restrict__ occ_scan, const unsigned* __restrict__ cnt,
+                                const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ tsum,
+                                const int* __restrict__ maxidx, const int* __restrict__ batch_of_index,
+                                const unsigned* __restrict__ feat, const unsigned* __restrict__ bitmap,
+                                const unsigned* __restrict__ rowptr, int S, int nx, int ny, int level0, float Wf, float Hf, float whx,
+                                float why, int C, int ldx, float* __restrict__ xout, float* __restrict__ npos, int* __restrict__ npix,
+                                int* __restrict__ nbatch, int* __restrict__ node_slot_out, int* __restrict__ slot2node,
+                                int* __restrict__ csr_src, int* __restrict__ csr_dxy, int blocks_fin) {
+    if ((int)blockIdx.x >= blocks_fin) {                     // CSR rows: one thread per slot, in their own blocks of the launch
+        const int s = ((int)blockIdx.x - blocks_fin) * blockDim.x + threadIdx.x;   // (one emit lane per feature wave would
+        if (s >= S) return;                                                      //  stall that whole wave behind it)
+        const unsigned c = cnt[s];
+        if (c == 0) return;
+        const unsigned* w = bitmap + (size_t)s * 3;
+        unsigned o = rowptr[occ_scan[s]];
+        const SlotPix pd = slot_pixel(sums, tsum, c, s, level0, Wf, Hf, whx, why, false);
+        for (int word = 0; word < 3; ++word) {
+            unsigned bits = w[word];
+            while (bits) {
+                const int bit = __ffs(bits) - 1 + word * 32;
+                bits &= bits - 1;
+                const int dx = bit % 5 - 2, dy = (bit / 5) % 5 - 2, dp = bit / 25 - 1;
+                const int ss = s + dx + nx * dy + nx * ny * dp;
+                const SlotPix ps = slot_pixel(sums, tsum, cnt[ss], ss, level0, Wf, Hf, whx, why, false);
+                csr_src[o] = (int)occ_scan[ss];                              // sources in bit order = slot order
+                csr_dxy[o] = ((ps.qx - pd.qx) & 0xffff) | ((ps.qy - pd.qy) << 16);   // pos[src] - pos[dst] in pixels
+                ++o;
+            }
+        }
+        return;
+    }
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)S * C) return;
+    const int s = (int)(t / C), ch = (int)(t % C);
+    const unsigned c = cnt[s];
+    if (c == 0) { if (ch == 0) slot2node[s] = -1; return; }
+    const int j = (int)occ_scan[s];
+    float v = MODE == 1 ? __fdiv_rn(__uint_as_float(feat[t]), (float)c) : (MODE == 2 ? __uint_as_float(feat[t]) : evad_ord2f(feat[t]));
+    xout[(size_t)j * ldx + ch] = v;
+    if (ch == 0) {
+        slot2node[s] = j; node_slot_out[j] = s;
+        const SlotPix p = slot_pixel(sums, tsum, c, s, level0, Wf, Hf, whx, why, true);
+        npos[3 * j] = p.ox; npos[3 * j + 1] = p.oy; npos[3 * j + 2] = p.mt;
+        npix[2 * j] = p.qx; npix[2 * j + 1] = p.qy;
+        nbatch[j] = batch_of_index[maxidx[s] - 1];
+        xout[(size_t)j * ldx + C] = p.ox; xout[(size_t)j * ldx + C + 1] = p.oy;
+        for (int k = C + 2; k < ldx; ++k) xout[(size_t)j * ldx + k] = 0.f;
+    }
+}
+
+extern "C" int eventad_pool_finalize_edges(const uint32_t* feat, const uint64_t* sums, const double* tsum, const uint32_t* cnt,
+                                           const int32_t* maxidx, const int32_t* batch_of_index, const uint32_t* bitmap, int nx,
+                                           int ny, int B, int C, int feat_mode, int level0, int W, int H, float wh_inv_x,
+                                           float wh_inv_y, uint32_t* occ_scan, float* xout, int ldx, float* npos_out,
+                                           int32_t* npix_out, int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node,
+                                           int32_t* n_out_dev, uint32_t* rowptr, int32_t* csr_src, int32_t* csr_dxy,
+                                           int32_t* e_out_dev, void* stream) {
+    if (!feat || !sums || !tsum || !cnt || !maxidx || !batch_of_index || !bitmap || !occ_scan || !xout || !npos_out ||
+        !npix_out || !nbatch_out || !node_slot_out || !slot2node || !n_out_dev || !rowptr || !csr_src || !csr_dxy || !e_out_dev ||
+        C < 1 || ldx < C + 2 || nx <= 0 || ny <= 0 || B <= 0)
+        return EVAD_ERR_ARG;
+    const int S = nx * ny * (B + 1);
+    if (S > 131072) return EVAD_ERR_ARG;                     // larger tables: eventad_pool_finalize + eventad_pool_edges_emit
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_slot_scans_small, dim3(1), dim3(1024), 0, st, cnt, bitmap, S, S, occ_scan, rowptr, n_out_dev, e_out_dev);
+    const unsigned blocks_fin = evad_blocks((long long)S * C, 256);
+    dim3 grid(blocks_fin + evad_blocks(S, 256));
+#define EVAD_FE(MODE) hipLaunchKernelGGL(k_finalize_emit<MODE>, grid, dim3(256), 0, st, occ_scan, cnt, (const unsigned long long*)sums, \
+                       (const unsigned long long*)tsum, maxidx, batch_of_index, feat, bitmap, rowptr, S, nx, ny, level0, (float)W, (float)H, \
+                       wh_inv_x, wh_inv_y, C, ldx, xout, npos_out, npix_out, nbatch_out, node_slot_out, slot2node, csr_src, csr_dxy, (int)blocks_fin)
+    if (feat_mode == 1) EVAD_FE(1); else if (feat_mode == 2) EVAD_FE(2); else EVAD_FE(0);
+#undef EVAD_FE
+    return evad_last_error();
+}
+
 extern "C" int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t* deg, const int32_t* node_slot, int N,
                                            int max_num_neighbors, int nx, int ny, int B, uint32_t* bitmap, uint32_t* flags,
                                            void* stream) {

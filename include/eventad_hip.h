@@ -126,6 +126,16 @@ int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const doub
                           uint32_t* scan_tmp, float* xout, int ldx, float* npos_out, int32_t* npix_out,
                           int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node, int32_t* n_out_dev,
                           void* stream);
+/* eventad_pool_finalize + eventad_pool_edges_emit in two launches (tables of up to 131072 slots): one single-workgroup
+ * pass does both exclusive scans (slot occupancy = node numbering; popcount of the occupied slots' bitmap = CSR row
+ * pointers), one launch writes node attributes, features and CSR columns.  The bitmap must be complete (marked)
+ * before the call.  rowptr u32[S+2].  Outputs are bit-identical to the separate calls. */
+int eventad_pool_finalize_edges(const uint32_t* feat, const uint64_t* sums, const double* tsum, const uint32_t* cnt,
+                                const int32_t* maxidx, const int32_t* batch_of_index, const uint32_t* bitmap, int nx, int ny,
+                                int B, int C, int feat_mode, int level0, int W, int H, float wh_inv_x, float wh_inv_y,
+                                uint32_t* occ_scan, float* xout, int ldx, float* npos_out, int32_t* npix_out,
+                                int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node, int32_t* n_out_dev,
+                                uint32_t* rowptr, int32_t* csr_src, int32_t* csr_dxy, int32_t* e_out_dev, void* stream);
 int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t* deg, const int32_t* node_slot, int N,
                                 int max_num_neighbors, int nx, int ny, int B, uint32_t* bitmap, uint32_t* flags,
                                 void* stream);
