@@ -469,23 +469,35 @@ __global__ void k_edge_emit(const unsigned* __restrict__ bitmap, const int* __re
 __global__ __launch_bounds__(1024) void k_slot_scans_small(const unsigned* __restrict__ cnt, const unsigned* __restrict__ bitmap, int S,
                                                            int n_max, unsigned* __restrict__ occ_scan, unsigned* __restrict__ rowptr,
                                                            int* __restrict__ n_out, int* __restrict__ e_out) {
-    constexpr int IT = 8;
+    // A pass covers IT*1024 consecutive slots.  Loads are coalesced (thread t takes slots t, t+1024, ...) and all in
+    // flight together; the (occupied, degree) pairs go through LDS so that each thread then scans IT CONSECUTIVE
+    // slots, and the occupancy prefixes return through LDS for a coalesced store.
+    constexpr int IT = 20, CH = 1024 * IT;                   // level 0 at B = 8 (20160 slots) is one pass
+    __shared__ unsigned char s_vd[CH];                       // occupied << 7 | degree (<= 75)
+    __shared__ unsigned short s_pre[CH];                     // occupancy prefix inside the pass (< 20480)
     __shared__ unsigned wsum[16], wsum2[16];
     __shared__ unsigned carry_n, carry_e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) { carry_n = 0; carry_e = 0; }
     __syncthreads();
-    for (int base = 0; base < S; base += 1024 * IT) {
-        const int i0 = base + tid * IT;
-        unsigned v[IT], d[IT], sn = 0, se = 0;
-#pragma unroll
-        for (int k = 0; k < IT; ++k) v[k] = (i0 + k < S && cnt[i0 + k] > 0) ? 1u : 0u;
+    for (int base = 0; base < S; base += CH) {
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
-            d[k] = 0;
-            if (v[k]) { const unsigned* w = bitmap + (size_t)(i0 + k) * 3; d[k] = __popc(w[0]) + __popc(w[1]) + __popc(w[2]); }
-            sn += v[k]; se += d[k];
+            const int s = base + k * 1024 + tid;
+            unsigned char vd = 0;
+            if (s < S) {
+                const unsigned c = cnt[s];
+                const unsigned* w = bitmap + (size_t)s * 3;
+                const unsigned pc = __popc(w[0]) + __popc(w[1]) + __popc(w[2]);
+                vd = c > 0 ? (unsigned char)(0x80u | pc) : 0;
+            }
+            s_vd[k * 1024 + tid] = vd;
         }
+        __syncthreads();
+        unsigned v[IT], d[IT], sn = 0, se = 0;
+        const int l0 = tid * IT;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const unsigned x = s_vd[l0 + k]; v[k] = x >> 7; d[k] = x & 0x7fu; sn += v[k]; se += d[k]; }
         unsigned in_ = sn, ie = se;
         for (int dd = 1; dd < 64; dd <<= 1) {
             unsigned t = __shfl_up(in_, dd, 64), u = __shfl_up(ie, dd, 64);
@@ -495,14 +507,20 @@ __global__ __launch_bounds__(1024) void k_slot_scans_small(const unsigned* __res
         __syncthreads();
         unsigned bn = 0, be = 0, tn = 0, te = 0;
         for (int w = 0; w < 16; ++w) { if (w < wv) { bn += wsum[w]; be += wsum2[w]; } tn += wsum[w]; te += wsum2[w]; }
-        unsigned en = carry_n + bn + in_ - sn, ee = carry_e + be + ie - se;
+        unsigned en = bn + in_ - sn, ee = carry_e + be + ie - se;   // en: prefix inside the pass
+        const unsigned cn = carry_n;
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
-            if (i0 + k < S) occ_scan[i0 + k] = en;
-            if (v[k]) rowptr[en] = ee;
+            s_pre[l0 + k] = (unsigned short)en;
+            if (v[k]) rowptr[cn + en] = ee;
             en += v[k]; ee += d[k];
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int s = base + k * 1024 + tid;
+            if (s < S) occ_scan[s] = cn + s_pre[k * 1024 + tid];
+        }
         if (tid == 0) { carry_n += tn; carry_e += te; }
         __syncthreads();
     }
