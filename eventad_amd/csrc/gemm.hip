@@ -273,7 +273,7 @@ extern "C" int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int
 #define TG_MAXP 8
 struct TProb {
     const float* A; const float* B; float* C; const float* bias; float* part; int* cnt;
-    int lda, ldb, ldc, M, N, K, ta, tb, acc, relu, tiles_m, tiles_n, ksplit, kgroups, block0;
+    int lda, ldb, ldc, M, N, K, ta, tb, acc, relu, tiles_m, tiles_n, ksplit, kgroups, block0, keep_slabs;
 };
 struct TGroup { TProb p[TG_MAXP]; int n; };
 
@@ -391,7 +391,7 @@ __global__ void k_tile_reduce(TGroup g) {
     int pi = blockIdx.y;
     if (pi >= g.n) return;
     const TProb& P = g.p[pi];
-    if (P.kgroups == 1 || P.cnt) return;
+    if (P.kgroups == 1 || P.cnt || P.keep_slabs) return;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.M * P.N) return;
     int m = t / P.N, n = t % P.N;
@@ -407,7 +407,9 @@ __global__ void k_tile_reduce(TGroup g) {
  *   [0] A  [1] B  [2] part scratch f32[ceil(K/256)][M][N] (needed when K > 256)  [3] C  [4] bias (0 = none)  [5] lda  [6] ldb  [7] ldc  [8] M  [9] N  [10] K
  *   [11] trans_a  [12] trans_b  [13] accumulate  [14] relu
  *   [15] tile counters i32[ceil(M/32)*ceil(N/32)] (0 = none): zero on first use, left zero by every launch; with them the
- *        K > 256 slabs are summed by the last workgroup to reach each tile instead of by a second launch */
+ *        K > 256 slabs are summed by the last workgroup to reach each tile instead of by a second launch;
+ *        the value 1 = leave the slabs of a K > 256 product in `part` (f32[ceil(K/256)][M][N]) un-summed: the consumer adds them
+ *        (+ bias/accumulate are then the consumer's business too) */
 extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream) {
     if (n_prob < 1 || n_prob > TG_MAXP || !desc) return EVAD_ERR_ARG;
     TGroup g;
@@ -418,13 +420,14 @@ extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream)
         TProb& P = g.p[i];
         P.A = (const float*)d[0]; P.B = (const float*)d[1]; P.part = (float*)d[2]; P.C = (float*)d[3]; P.bias = (const float*)d[4];
         P.lda = (int)d[5]; P.ldb = (int)d[6]; P.ldc = (int)d[7]; P.M = (int)d[8]; P.N = (int)d[9]; P.K = (int)d[10];
-        P.ta = (int)d[11]; P.tb = (int)d[12]; P.acc = (int)d[13]; P.relu = (int)d[14]; P.cnt = (int*)d[15];
+        P.ta = (int)d[11]; P.tb = (int)d[12]; P.acc = (int)d[13]; P.relu = (int)d[14];
+        P.keep_slabs = d[15] == 1; P.cnt = P.keep_slabs ? nullptr : (int*)d[15];
         if (!P.A || !P.B || !P.C || P.M < 1 || P.N < 1 || P.K < 1 || (P.lda & 3) || (P.ldb & 3) || !al16(P.A) || !al16(P.B) ||
             P.ldc < P.N || P.lda < (P.ta ? P.M : P.K) || P.ldb < (P.tb ? P.K : P.N))
             return EVAD_ERR_ARG;
         P.tiles_m = (P.M + 31) / 32; P.tiles_n = (P.N + 31) / 32; P.ksplit = (P.K + 63) / 64; P.block0 = blocks;
         P.kgroups = (P.ksplit + 3) / 4;
-        if (P.kgroups > 1) { if (!P.part) return EVAD_ERR_ARG; if (!P.cnt && P.M * P.N > max_mn) max_mn = P.M * P.N; }
+        if (P.kgroups > 1) { if (!P.part) return EVAD_ERR_ARG; if (!P.cnt && !P.keep_slabs && P.M * P.N > max_mn) max_mn = P.M * P.N; }
         blocks += P.tiles_m * P.tiles_n * P.kgroups;
     }
     hipLaunchKernelGGL(k_tile_gemm, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);

@@ -400,7 +400,8 @@ extern "C" int eventad_gru_att_fwd_group(int n, const int64_t* d, void* stream) 
 
 struct StepBwdProb { const float* hn; const float* w; const float* alpha; const float* dsnext; const float* dhn_out;
                      const int* valid; float* dw; const float* dx_extra; const float* mask; const float* gates;
-                     const float* gh; const float* hprev; float* dgi; float* dgh; float* dsprev; int H; };
+                     const float* gh; const float* hprev; float* dgi; float* dgh; float* dsprev; int H;
+                     const float* ds_part; int ds_slabs; const float* dx_part; int dx_slabs; };
 struct StepBwdGroup { StepBwdProb p[3]; int n; };
 
 template <int CH>
@@ -416,6 +417,11 @@ __device__ __forceinline__ void step_bwd_body(const StepBwdProb& P) {
     for (int i = 0; i < CH; ++i) {
         const size_t t = (size_t)k * H + c + 32 * i;
         hn[i] = P.hn[t]; gs[i] = P.dsnext[t];
+        if (P.ds_part) {                                     // un-summed split-K slabs of the previous stage's dS product:
+            float v = 0.f;                                   // same order as k_tile_reduce (slabs ascending, then + C)
+            for (int q = 0; q < P.ds_slabs; ++q) v += P.ds_part[(size_t)q * NT * H + t];
+            gs[i] = v + gs[i];
+        }
         part += gs[i] * hn[i];
     }
 #pragma unroll
@@ -443,7 +449,11 @@ __device__ __forceinline__ void step_bwd_body(const StepBwdProb& P) {
         }
         s_c[k][j] = ds * th;
         // GRU cell backward (see k_gru_cell_bwd)
-        if (P.dx_extra) dh += P.mask ? P.dx_extra[t] * P.mask[t] : P.dx_extra[t];
+        if (P.dx_part) {
+            float dx = 0.f;
+            for (int q = 0; q < P.dx_slabs; ++q) dx += P.dx_part[(size_t)q * NT * H + t];
+            dh += P.mask ? dx * P.mask[t] : dx;
+        } else if (P.dx_extra) dh += P.mask ? P.dx_extra[t] * P.mask[t] : P.dx_extra[t];
         const float r = gt[j], z = gt[H + j], n = gt[2 * H + j];
         const float ghn = P.gh[(size_t)k * 3 * H + 2 * H + j];
         const float h = P.hprev[t];
@@ -467,18 +477,21 @@ __global__ __launch_bounds__(1024) void k_step_bwd(StepBwdGroup g) {
     if (P.H == 256) step_bwd_body<8>(P); else step_bwd_body<1>(P);
 }
 
-/* desc: HOST array, 16 int64 per problem: [0] hn [1] attention w [2] alpha [3] dsnext [4] dhn_out (0 = none)
+/* desc: HOST array, 20 int64 per problem: [0] hn [1] attention w [2] alpha [3] dsnext [4] dhn_out (0 = none)
  * [5] valid [6] dw accumulator [7] dx_extra (0 = none) [8] mask (0 = none) [9] gates [10] gh [11] hprev
- * [12] dgi out [13] dgh out [14] dsprev out [15] H. */
+ * [12] dgi out [13] dgh out [14] dsprev out [15] H [16] dsnext slabs (0 = none) [17] their number [18] dx_extra slabs
+ * (0 = none; replace [7]) [19] their number.  Slabs are f32[n][32][H], the un-summed split-K output of eventad_gemm_group. */
 extern "C" int eventad_gru_att_bwd_group(int n, const int64_t* d, void* stream) {
     if (n < 1 || n > 3 || !d) return EVAD_ERR_ARG;
     StepBwdGroup g; g.n = n;
     for (int i = 0; i < n; ++i) {
-        const int64_t* q = d + 16 * i; StepBwdProb& P = g.p[i];
+        const int64_t* q = d + 20 * i; StepBwdProb& P = g.p[i];
         P.hn = (const float*)q[0]; P.w = (const float*)q[1]; P.alpha = (const float*)q[2]; P.dsnext = (const float*)q[3];
         P.dhn_out = (const float*)q[4]; P.valid = (const int*)q[5]; P.dw = (float*)q[6]; P.dx_extra = (const float*)q[7];
         P.mask = (const float*)q[8]; P.gates = (const float*)q[9]; P.gh = (const float*)q[10]; P.hprev = (const float*)q[11];
         P.dgi = (float*)q[12]; P.dgh = (float*)q[13]; P.dsprev = (float*)q[14]; P.H = (int)q[15];
+        P.ds_part = (const float*)q[16]; P.ds_slabs = (int)q[17]; P.dx_part = (const float*)q[18]; P.dx_slabs = (int)q[19];
+        if ((P.ds_part && (P.ds_slabs < 1 || P.ds_slabs > 8)) || (P.dx_part && (P.dx_slabs < 1 || P.dx_slabs > 8))) return EVAD_ERR_ARG;
         if (!P.hn || !P.w || !P.alpha || !P.dsnext || !P.valid || !P.dw || !P.gates || !P.gh || !P.hprev || !P.dgi || !P.dgh ||
             !P.dsprev || (P.H != 256 && P.H != 32))
             return EVAD_ERR_ARG;
@@ -516,12 +529,16 @@ __global__ void k_fuse_out(const float* __restrict__ F1r, const float* __restric
     }
 }
 
-__global__ void k_loss_sum(const float* __restrict__ loss_rows, int R, float* __restrict__ loss) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) s += loss_rows[r];
-        *loss = s;
+__global__ __launch_bounds__(256) void k_loss_sum(const float* __restrict__ loss_rows, int R, float* __restrict__ loss) {
+    __shared__ float s_l[1024];                              // rows are fetched in parallel, added in row order by one thread
+    float s = 0.f;
+    for (int base = 0; base < R; base += 1024) {
+        for (int i = threadIdx.x; i < 1024 && base + i < R; i += 256) s_l[i] = loss_rows[base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) { const int m = min(1024, R - base); for (int r = 0; r < m; ++r) s += s_l[r]; }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *loss = s;
 }
 
 extern "C" int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
@@ -529,7 +546,7 @@ extern "C" int eventad_fuse_out(const float* F1r, const float* D2, const float* 
                                 void* stream) {
     if (!F1r || !Wo || !bo || !target || !valid || !logits || !dlog || !loss_rows || !loss || R <= 0) return EVAD_ERR_ARG;
     hipLaunchKernelGGL(k_fuse_out, dim3(R), dim3(64), 0, (hipStream_t)stream, F1r, D2, Wo, bo, target, valid, R, logits, dlog, loss_rows);
-    hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_rows, R, loss);
+    hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, R, loss);
     return evad_last_error();
 }
 
@@ -587,7 +604,18 @@ __global__ __launch_bounds__(256) void k_colsum_g(ColGroup g) {
     int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     if (blockIdx.x * 64 >= N) return;
     float s = 0.f;
-    if (n < N) for (int r = w; r < g.R; r += 4) s += g.A[pi][(size_t)r * g.lda[pi] + n];
+    if (n < N) {
+        const float* a = g.A[pi] + n; const size_t ld = (size_t)g.lda[pi];
+        int r = w;
+        for (; r + 28 < g.R; r += 32) {                      // 8 rows in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a[(size_t)(r + 4 * u) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < g.R; r += 4) s += a[(size_t)r * ld];
+    }
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
     if (w == 0 && n < N) g.out[pi][n] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];

@@ -34,6 +34,10 @@ def _rp(t):
 
 
 _TILE_CNT = os.environ.get("EVENTAD_TILE_CNT", "0") == "1"
+# chain products with K = 768: leave the split-K slabs for the consuming fused kernel instead of a reduce launch per stage.
+# Measured on C2 (same box, A/B): head graph 0.695 ms with, 0.630 ms without -- the extra loads sit on the one-workgroup
+# critical path and cost more than the 5 us launch they save.  Off.
+_KEEP_SLABS = os.environ.get("EVENTAD_KEEP_SLABS", "0") == "1"
 
 
 class NativeHead:
@@ -110,20 +114,22 @@ class NativeHead:
 
     # ------------------------------------------------------------ launch helpers
     def _gg(self, *probs):
-        """One grouped-GEMM launch.  prob = (ta, tb, A, lda, B, ldb, C, ldc, M, N, K[, bias[, relu[, acc]]])."""
+        """One grouped-GEMM launch.  prob = (ta, tb, A, lda, B, ldb, C, ldc, M, N, K[, bias[, relu[, acc[, keep]]]]);
+        keep = leave the split-K slabs of a K > 256 product un-summed in self.w["part"][i] for the consumer."""
         d = (ctypes.c_int64 * (16 * len(probs)))()
         for i, pr in enumerate(probs):
             ta, tb, A, lda, Bm, ldb, C, ldc, M, N, K = pr[:11]
             bias = pr[11] if len(pr) > 11 else None
             relu = pr[12] if len(pr) > 12 else 0
             acc = pr[13] if len(pr) > 13 else 0
+            keep = (pr[14] if len(pr) > 14 else 0) and _KEEP_SLABS
             if K > 256 and ((K + 255) // 256) * M * N > self.w["part"][i].numel():
                 raise RuntimeError("grouped GEMM: split-K scratch too small for M=%d N=%d K=%d" % (M, N, K))
             if K > 256 and ((M + 31) // 32) * ((N + 31) // 32) > self.w["cnt"][i].numel():
                 raise RuntimeError("grouped GEMM: tile-counter buffer too small for M=%d N=%d" % (M, N))
             d[16 * i:16 * i + 16] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr() if K > 256 else 0, C.data_ptr(),
                                      bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu,
-                                     self.w["cnt"][i].data_ptr() if (K > 256 and _TILE_CNT) else 0]
+                                     1 if (keep and K > 256) else (self.w["cnt"][i].data_ptr() if (K > 256 and _TILE_CNT) else 0)]
         call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
 
     @staticmethod
@@ -232,26 +238,44 @@ class NativeHead:
         w["dwatt"].zero_()
         # reverse wavefront: stage b runs layer 1 + the coordinate GRU on clip b and layer 0 on clip b+1 (whose
         # dX1 and dS0 come out of the previous stage's GEMMs): fused attention+cell backward, then one grouped GEMM
+        # The [32,768]x[768,256] products of the chain have 3 split-K slabs; with _KEEP_SLABS the NEXT stage's fused kernel
+        # adds them while it loads (same order as the reduce kernel: same bits) instead of a reduce launch per stage.
+        SL = 3                                                  # ceil(768 / 256)
+        p1 = p0 = px = None                                    # slabs of dS1 / dS0 / dX1 from the previous stage
         for b in range(B - 1, -2, -1):
             steps, gemms = [], []
+            i1 = i0 = ix = None
             if b >= 0:
                 r0, r1 = b * NT, (b + 1) * NT
                 vb = w["valid"][r0:r1]
                 steps += [[w["H1n"][r0:r1], watt, w["AL1"][r0:r1], d1, w["dH1o"][r0:r1], vb, w["dwatt1"], None, None,
-                           w["G1"][r0:r1], w["GH1"][r0:r1], w["S1"][r0:r1], w["dGI1"][r0:r1], w["dGH1"][r0:r1], n1, 256],
+                           w["G1"][r0:r1], w["GH1"][r0:r1], w["S1"][r0:r1], w["dGI1"][r0:r1], w["dGH1"][r0:r1], n1, 256,
+                           p1, SL if p1 is not None else 0, None, 0],
                           [w["HCn"][r0:r1], wattc, w["ALC"][r0:r1], dc, w["dHCo"][r0:r1], vb, gattc, None, None,
-                           w["GC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["dGIC"][r0:r1], w["dGHC"][r0:r1], nc, 32]]
-                gemms += [(0, 0, w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, None, 0, 1),
-                          (0, 0, w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, None, 0, 1),
-                          (0, 0, w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768)]
+                           w["GC"][r0:r1], w["GHC"][r0:r1], w["SC"][r0:r1], w["dGIC"][r0:r1], w["dGHC"][r0:r1], nc, 32,
+                           None, 0, None, 0]]
+                if b > 0:                                      # dS of the initial state (clip 0) is never used
+                    i1 = len(gemms)
+                    gemms += [(0, 0, w["dGH1"][r0:r1], 768, P[ev + "weight_hh_l1"], 256, n1, 256, NT, 256, 768, None, 0, 1, 1),
+                              (0, 0, w["dGHC"][r0:r1], 96, P[co + "weight_hh_l0"], 32, nc, 32, NT, 32, 96, None, 0, 1)]
+                ix = len(gemms)
+                gemms += [(0, 0, w["dGI1"][r0:r1], 768, P[ev + "weight_ih_l1"], 256, w["dX1"], 256, NT, 256, 768, None, 0, 0, 1)]
             if b + 1 < B:
                 q0, q1 = (b + 1) * NT, (b + 2) * NT
                 steps += [[w["H0n"][q0:q1], watt, w["AL0"][q0:q1], d0, None, w["valid"][q0:q1], w["dwatt0"], w["dX1"],
                            self.D1[q0:q1] if train else None, w["G0"][q0:q1], w["GH0"][q0:q1], w["S0"][q0:q1],
-                           w["dGI0"][q0:q1], w["dGH0"][q0:q1], n0, 256]]
-                gemms += [(0, 0, w["dGH0"][q0:q1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, None, 0, 1)]
-            self._desc("eventad_gru_att_bwd_group", 16, steps)
-            self._gg(*gemms)
+                           w["dGI0"][q0:q1], w["dGH0"][q0:q1], n0, 256,
+                           p0, SL if p0 is not None else 0, px, SL if px is not None else 0]]
+                if b + 1 > 0:
+                    i0 = len(gemms)
+                    gemms += [(0, 0, w["dGH0"][q0:q1], 768, P[ev + "weight_hh_l0"], 256, n0, 256, NT, 256, 768, None, 0, 1, 1)]
+            self._desc("eventad_gru_att_bwd_group", 20, steps)
+            if gemms:
+                self._gg(*gemms)
+            # slabs are per problem slot of the launch; the next stage reads them before its own launch overwrites them
+            p1 = w["part"][i1] if (i1 is not None and _KEEP_SLABS) else None
+            px = w["part"][ix] if (ix is not None and _KEEP_SLABS) else None
+            p0 = w["part"][i0] if (i0 is not None and _KEEP_SLABS) else None
             if b >= 0:
                 d1, n1, o1 = n1, o1, n1
                 dc, nc, oc = nc, oc, nc

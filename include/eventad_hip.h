@@ -196,9 +196,10 @@ int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid,
  * fwd desc = HOST array, 12 int64 per problem: [0] gi [1] gh [2] hprev (= the state the attention keeps for invalid
  * tracks) [3] gates out [4] hn out [5] dropout mask(0=none) [6] xdrop out(0=none) [7] attention w [8] alpha out
  * [9] snext out [10] valid i32[32] [11] H (256|32).
- * bwd desc = 16 int64 per problem: [0] hn [1] attention w [2] alpha [3] dsnext [4] dhn_out(0=none) [5] valid
+ * bwd desc = 20 int64 per problem: [0] hn [1] attention w [2] alpha [3] dsnext [4] dhn_out(0=none) [5] valid
  * [6] dw accumulator [7] dx_extra(0=none) [8] mask(0=none) [9] gates [10] gh [11] hprev [12] dgi out [13] dgh out
- * [14] dsprev out [15] H. */
+ * [14] dsprev out [15] H [16] dsnext slabs f32[n][32][H] (0=none): dsnext := (sum of slabs, in order) + dsnext [17] n
+ * [18] dx_extra slabs f32[n][32][H] (0=none): dx_extra := sum of slabs (the [7] pointer is then ignored) [19] n. */
 int eventad_gru_att_fwd_group(int n_prob, const int64_t* desc, void* stream);
 int eventad_gru_att_bwd_group(int n_prob, const int64_t* desc, void* stream);
 /* Up to 8 independent small GEMMs per launch (one workgroup per 32x32 tile, its 4 waves split K in 64-deep
@@ -206,7 +207,8 @@ int eventad_gru_att_bwd_group(int n_prob, const int64_t* desc, void* stream);
  * [2] part scratch f32[ceil(K/256)][M][N] (only when K > 256) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K
  * [11] trans_a [12] trans_b [13] accumulate [14] relu [15] tile counters i32[ceil(M/32)*ceil(N/32)] (0 = none; zero
  * on first use, every launch leaves them zero): with them the slabs of a K > 256 product are summed, in slab order,
- * by the last workgroup to reach the tile instead of by a second launch. */
+ * by the last workgroup to reach the tile instead of by a second launch; the value 1 = leave the slabs of a K > 256
+ * product un-summed in `part` for a consumer that adds them itself (eventad_gru_att_bwd_group does). */
 int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream);
 /* Up to 3 GRU cells per launch.  desc = HOST array, 12 int64 per cell: fwd [0] gi [1] gh [2] hprev [3] gates
  * [4] hnew [5] mask(0) [6] xdrop(0) [7] H; bwd [0] dhn [1] dx_extra(0) [2] mask(0) [3] gates [4] gh [5] hprev
