@@ -362,14 +362,23 @@ __device__ __forceinline__ void step_fwd_body(const StepProb& P) {
     for (int d = 16; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
     if (c == 0) s_s[k] = part;
     __syncthreads();
-    float m = -3.4e38f;
+    // softmax over the valid tracks: 32 lanes of wave 0 (one exp per track instead of 64 per thread), shared through LDS
+    __shared__ float s_al[NT];
+    if (tid < 64) {
+        const int q = tid & 31;
+        const bool vq = s_v[q] != 0;
+        float m = vq ? s_s[q] : -3.4e38f;
 #pragma unroll
-    for (int q = 0; q < NT; ++q) if (s_v[q]) m = fmaxf(m, s_s[q]);
-    float sum = 0.f;
+        for (int d = 16; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        const float e = vq ? expf(s_s[q] - m) : 0.f;
+        float sum = e;
 #pragma unroll
-    for (int q = 0; q < NT; ++q) if (s_v[q]) sum += expf(s_s[q] - m);
+        for (int d = 16; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        if (tid < NT) s_al[q] = vq ? e / sum : 0.f;
+    }
+    __syncthreads();
     const bool v = s_v[k] != 0;
-    const float al = v ? expf(s_s[k] - m) / sum : 0.f;
+    const float al = s_al[k];
     if (c == 0) P.alpha[k] = al;
 #pragma unroll
     for (int i = 0; i < CH; ++i) P.snext[(size_t)k * H + c + 32 * i] = v ? hn[i] * al : hp[i];
