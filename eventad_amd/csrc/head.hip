@@ -33,11 +33,15 @@ __global__ void k_head_tables(const float* __restrict__ bbox, const long long* _
     X[(size_t)row * 64 + j] = f;
     float s = f;                                                            // torch.sum(curr_feature) == 0 ?
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    int found = -1;                                          // FIRST matching box row: 64 rows tested per step
+    if (k >= 1 && k < FEAT_T)
+        for (int base = 0; base < M && found < 0; base += 64) {
+            const int m = base + j;
+            const bool hit = m < M && (int)bbox_batch[m] == b && bbox[(size_t)m * 6 + 5] == (float)k;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) found = base + __ffsll((long long)mask) - 1;
+        }
     if (j == 0) {
-        int found = -1;
-        if (k >= 1 && k < FEAT_T)
-            for (int m = 0; m < M; ++m)
-                if ((int)bbox_batch[m] == b && bbox[(size_t)m * 6 + 5] == (float)k) { found = m; break; }
         float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f; int t = 0;
         if (found >= 0) {
             const float* bb = bbox + (size_t)found * 6;

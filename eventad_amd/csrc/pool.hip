@@ -194,9 +194,12 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     float my = NEG;
     unsigned n = 0; unsigned long long sx = 0, sy = 0, ts = 0; int mi = 0;         // mi = max member id + 1
     auto member = [&](int r) {
-        if (node_slot[r] != slot) return;
-        float px = posn_s[3 * r], py = posn_s[3 * r + 1];
-        int k = key_s[r];
+        // all index / position loads of the member go out together; the slot test only gates the map reads
+        const int ns = node_slot[r];
+        const float px = posn_s[3 * r], py = posn_s[3 * r + 1], pt = posn_s[3 * r + 2];
+        const int k = key_s[r], id = sid[r];
+        const float yv = y2[(size_t)r * 16 + q];
+        if (ns != slot) return;
         int b = k / (W * H);
         int x0, y0; float fx, fy;
         bilin_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
@@ -213,16 +216,25 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
         add(vx0 && vy0, p00, w00); add(vx1 && vy0, p00 + 64, w01);
         add(vx0 && vy1, p00 + (size_t)map_w * 64, w10); add(vx1 && vy1, p00 + (size_t)map_w * 64 + 64, w11);
         mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-        my = fmaxf(my, y2[(size_t)r * 16 + q]);
+        my = fmaxf(my, yv);
         if (q == 0) { ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H);
-                      ts += (unsigned long long)llrintf(posn_s[3 * r + 2] * 1099511627776.f); mi = max(mi, sid[r] + 1); }
+                      ts += (unsigned long long)llrintf(pt * 1099511627776.f); mi = max(mi, id + 1); }
     };
     if (plane < B) {
         const int x0 = vx_lo[cx], x1 = vx_lo[cx + 1], y0 = vy_lo[cy], y1 = vy_lo[cy + 1];
-        for (int py = y0; py < y1; ++py) {
-            int base = W * (py + H * plane);
-            int ra = (int)pix_start[base + x0], rb = (int)pix_start[base + x1];   // a voxel row is contiguous in sorted order
-            for (int r = ra + grp; r < rb; r += 4) member(r);
+        for (int yb = y0; yb < y1; yb += 8) {               // the CSR bounds of 8 pixel rows load together
+            int ra[8], rb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ra[i] = 0; rb[i] = 0;
+                if (yb + i < y1) {
+                    const int base = W * (yb + i + H * plane);
+                    ra[i] = (int)pix_start[base + x0]; rb[i] = (int)pix_start[base + x1];   // a voxel row is contiguous in sorted order
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                for (int r = ra[i] + grp; r < rb[i]; r += 4) member(r);
         }
     }
     const int n_ovf = (int)counters[2];
