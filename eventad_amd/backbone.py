@@ -42,10 +42,10 @@ class NativeBackbone:
         self._ws_key = None
         # edge-search kernel: -1 = thread per event, ELL row in registers (fastest on C2: 130 us); >0 = LDS-staged strips of
         # that many pixels (139 us at 64); 0 = batched prefetch (175 us).  All bit-identical (tools/microbench_ell.py).
-        # edge-search kernel (see eventad_build_ell); None = by expected window occupancy: the row-scan kernel (-6) for
-        # sparse windows, the register-row spiral walk (-1, early exit after 16 neighbours) for dense ones
+        # edge-search kernel (see eventad_build_ell); None = by expected window occupancy: the row scan (1) for sparse
+        # windows, the register-row spiral walk (0, early exit after 16 neighbours) for dense ones
         v = os.environ.get("EVENTAD_ELL_VARIANT")
-        self.strip_width = int(v) if v else None
+        self.ell_variant = int(v) if v else None
         self.fused_mark = True         # pool1 edge bitmap filled by the edge search itself: 172 us vs 134 + 98 us separate (C2)
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
@@ -237,11 +237,11 @@ class NativeBackbone:
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
              ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), 3 * L0_.S, st)     # also clears counters, histogram, pool1 bitmap
-        sw = self.strip_width
+        sw = self.ell_variant
         if sw is None:
             window = (2 * g.radius_px + 1) ** 2 * N / max(B * g.W * g.H, 1)         # mean events per search window
-            sw = -6 if (g.radius_px in (1, 3) and window < 64) else -1
-        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]) if (self.fused_mark or sw) else None,
+            sw = 1 if (g.radius_px in (1, 3) and window < 64) else 0
+        self._c("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]),
              ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],

@@ -452,89 +452,6 @@ __global__ __launch_bounds__(256) void k_build_ell(const int* __restrict__ sid, 
     deg[r] = nn;
 }
 
-// The edge search is bound by dependent memory round trips, not bytes: per spiral step the reference
-// kernel loads the FIFO head, then id, then timestamp, one after the other.  Here a thread fetches the
-// pixel-CSR offsets of 8 spiral steps together (16 independent loads), then the newest entry of each of
-// those 8 segments together (8 independent 8-byte {id, t} loads); only deeper entries of a segment are
-// dependent loads.  ~3 round trips per 8 steps instead of ~24.  Afterwards the emitted edges set their
-// source-voxel bit in the destination voxel's pool1 neighbour bitmap (replaces a second pass over the
-// ELL, pool.hip k_mark_ell); voxel coordinates come pre-decomposed so no integer division is needed.
-#define ELL_GROUP 8
-__global__ __launch_bounds__(256) void k_build_ell_g(const int2* __restrict__ ev2, const int* __restrict__ key_s,
-                                                     const unsigned* __restrict__ start, const int16_t* __restrict__ spiral,
-                                                     const unsigned* flags_in, int N, int W, int H, int steps, int Q, int dt_max,
-                                                     int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
-                                                     int* __restrict__ deg, const int* __restrict__ node_slot,
-                                                     const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
-                                                     unsigned* flags) {
-    constexpr int MAXNB = 16;
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
-    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
-    const int k = key_s[r];
-    const int2 mine = ev2[r];
-    const int me = mine.x, ts = mine.y;
-    const int x = k % W, y = (k / W) % H, plane_base = k - x - W * y;
-    int nb[MAXNB]; int stp[MAXNB];
-#pragma unroll
-    for (int e = 0; e < MAXNB; ++e) { nb[e] = 0; stp[e] = 0; }
-    nb[0] = r;
-    int nn = 1;
-    auto emit = [&](int s, int i) {                           // static indexing keeps nb/stp in registers
-#pragma unroll
-        for (int e = 1; e < MAXNB; ++e) if (e == nn) { nb[e] = s; stp[e] = i; }
-        ++nn;
-    };
-    for (int i0 = 0; i0 < steps && nn < MAXNB; i0 += ELL_GROUP) {
-        int st[ELL_GROUP], en[ELL_GROUP];
-#pragma unroll
-        for (int u = 0; u < ELL_GROUP; ++u) {
-            st[u] = 0; en[u] = 0;
-            int i = i0 + u;
-            if (i < steps) {
-                int xn = x + spiral[2 * i], yn = y + spiral[2 * i + 1];
-                if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
-                    int p = plane_base + xn + W * yn;
-                    st[u] = (int)start[p]; en[u] = (int)start[p + 1];
-                }
-            }
-        }
-        int2 head[ELL_GROUP];
-#pragma unroll
-        for (int u = 0; u < ELL_GROUP; ++u) head[u] = en[u] > st[u] ? ev2[en[u] - 1] : make_int2(0, 0);
-#pragma unroll
-        for (int u = 0; u < ELL_GROUP; ++u) {
-            if (nn < MAXNB) {
-                const int lo = max(st[u], en[u] - Q);
-                for (int s = en[u] - 1; s >= lo; --s) {
-                    int2 c = (s == en[u] - 1) ? head[u] : ev2[s];
-                    if (me > c.x) {
-                        if ((float)(ts - c.y) > (float)dt_max) { if (monotone) break; else continue; }
-                        emit(s, i0 + u);
-                        if (nn >= MAXNB) break;
-                    }
-                }
-            }
-        }
-    }
-    // ELL row: 64 B of sources + 32 B of steps, written as whole vectors
-    int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
-    rp[0] = make_int4(nb[0], nb[1], nb[2], nb[3]); rp[1] = make_int4(nb[4], nb[5], nb[6], nb[7]);
-    rp[2] = make_int4(nb[8], nb[9], nb[10], nb[11]); rp[3] = make_int4(nb[12], nb[13], nb[14], nb[15]);
-    uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
-    sp4[0] = make_uint4(stp[0] | stp[1] << 16, stp[2] | stp[3] << 16, stp[4] | stp[5] << 16, stp[6] | stp[7] << 16);
-    sp4[1] = make_uint4(stp[8] | stp[9] << 16, stp[10] | stp[11] << 16, stp[12] | stp[13] << 16, stp[14] | stp[15] << 16);
-    deg[r] = nn;
-    if (bitmap) {
-        const int my_slot = node_slot[r], my_vox = node_vox[r];
-        int vs[MAXNB];
-#pragma unroll
-        for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[nb[e]] : my_vox;      // independent gathers
-#pragma unroll
-        for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
-    }
-}
-
 // Thread-per-event walk with (a) the spiral table read through scalar loads and (b) the ELL row kept in
 // registers and written once as 4 x int4 + 2 x uint4.  Measured with PMC counters on C2, the plain walk
 // issues ~620 vector-memory instructions per wave, a third of them 2- and 4-byte scattered stores; on
@@ -592,547 +509,6 @@ __global__ __launch_bounds__(256) void k_build_ell_reg(const int2* __restrict__ 
 #pragma unroll
         for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS-staged edge search.  The thread-per-event kernels above are bound by divergence-amplified memory
-// round trips (every spiral step is a dependent load chain and a wave pays the longest chain of its 64
-// lanes: ~200 round trips per wave at C2).  Here one wave owns a strip of SW pixels of one sensor row:
-// it stages the pixel-CSR offsets of the strip's (2R+1) x (SW+2R) window and the {id,t} entries of those
-// pixels (2R+1 contiguous ranges of the sorted event array) in LDS with coalesced loads, then every
-// event of the strip walks its spiral against LDS only.  Strips whose window holds more than ELL_CAP
-// entries read the entries from global memory instead (same code path, uniform branch).
-// Optionally marks the pool1 neighbour bitmap per edge (voxel coordinates staged in LDS too).
-#define ELL_CAP 1024
-template <bool MARK>
-__global__ __launch_bounds__(64) void k_build_ell_strip(const int2* __restrict__ ev2, const int* __restrict__ key_s,
-                                                        const unsigned* __restrict__ start, const int16_t* __restrict__ spiral,
-                                                        const unsigned* flags_in, int W, int H, int R, int SW, int steps, int Q,
-                                                        int dt_max, int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
-                                                        int* __restrict__ deg, const int* __restrict__ node_slot,
-                                                        const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
-                                                        unsigned* flags) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
-    constexpr int MAXNB = 16;
-    const int D = 2 * R + 1, cols = SW + 2 * R + 1;          // offsets per window row (one more than pixels)
-    int* s_off = s_dyn;                                       // [D][cols]
-    int* s_pre = s_off + D * cols;                            // [D+1] LDS position of each window row's entries
-    int2* s_ev = (int2*)(s_pre + ((D + 1 + 3) & ~3));         // [ELL_CAP]
-    int* s_vox = (int*)(s_ev + ELL_CAP);                      // [ELL_CAP] (MARK only)
-    const int lane = threadIdx.x;
-    const int strips = (W + SW - 1) / SW;
-    const int strip = blockIdx.x % strips, rowid = blockIdx.x / strips;     // rowid = y + H*b
-    const int y = rowid % H, xa = strip * SW, xb = min(xa + SW, W);
-    const int plane_base = (rowid - y) * W;                                  // W*H*b
-    const int own0 = (int)start[plane_base + W * y + xa], own1 = (int)start[plane_base + W * y + xb];
-    if (own1 == own0) return;                                                // no events in this strip
-    for (int t = lane; t < D * cols; t += 64) {
-        int j = t / cols, i = t % cols, yy = y + j - R;
-        int xx = min(max(xa - R + i, 0), W);
-        s_off[t] = (yy >= 0 && yy < H) ? (int)start[plane_base + W * yy + xx] : 0;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        int acc = 0;
-        for (int j = 0; j < D; ++j) { s_pre[j] = acc; acc += s_off[j * cols + cols - 1] - s_off[j * cols]; }
-        s_pre[D] = acc;
-    }
-    __syncthreads();
-    const bool staged = s_pre[D] <= ELL_CAP;
-    if (staged) {
-        for (int j = 0; j < D; ++j) {
-            int g0 = s_off[j * cols], len = s_off[j * cols + cols - 1] - g0, p0 = s_pre[j];
-            for (int t = lane; t < len; t += 64) {
-                s_ev[p0 + t] = ev2[g0 + t];
-                if (MARK) s_vox[p0 + t] = node_vox[g0 + t];
-            }
-        }
-    }
-    __syncthreads();
-    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
-    for (int r = own0 + lane; r < own1; r += 64) {
-        const int2 mine = staged ? s_ev[s_pre[R] + (r - s_off[R * cols])] : ev2[r];
-        const int me = mine.x, ts = mine.y;
-        const int x = key_s[r] % W;
-        const int my_slot = MARK ? node_slot[r] : 0;
-        const int my_vox = MARK ? (staged ? s_vox[s_pre[R] + (r - s_off[R * cols])] : node_vox[r]) : 0;
-        int* row = ell_src + (size_t)r * MAXNB;
-        uint16_t* srow = ell_step + (size_t)r * MAXNB;
-        row[0] = r; srow[0] = 0;
-        int nn = 1;
-        for (int i = 0; i < steps && nn < MAXNB; ++i) {
-            const int dx = c_spiral[2 * i], dy = c_spiral[2 * i + 1];
-            const int j = dy + R, c = x - (xa - R) + dx;                     // window row / column of the neighbour pixel
-            const int st = s_off[j * cols + c], en = s_off[j * cols + c + 1];
-            const int lo = max(st, en - Q);
-            const int rel = s_pre[j] - s_off[j * cols];                      // LDS index = global position + rel
-            for (int sp = en - 1; sp >= lo; --sp) {
-                const int2 cnd = staged ? s_ev[sp + rel] : ev2[sp];
-                if (me > cnd.x) {
-                    if ((float)(ts - cnd.y) > (float)dt_max) { if (monotone) break; else continue; }
-                    row[nn] = sp; srow[nn] = (uint16_t)i;
-                    if (MARK) evad_mark_edge_packed(staged ? s_vox[sp + rel] : node_vox[sp], my_vox, my_slot, bitmap, flags);
-                    if (++nn >= MAXNB) break;
-                }
-            }
-        }
-        deg[r] = nn;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row-parallel edge search: LPE lanes per destination event, one lane per window row.
-// PMC counters on the thread-per-event walk show ~400 dependent vector-memory round trips per wave (a
-// wave pays the longest chain of its 64 lanes at each of the (2R+1)^2 spiral steps) and 79 % of wave
-// time in s_waitcnt.  A window row, however, is ONE contiguous range of the pixel-sorted event array:
-// a lane fetches the 2R+2 pixel-CSR offsets of its row together, then the first 8 {id,t} entries of the
-// row together into LDS, and evaluates the validity rules of ev_graph.cu:56-74 (id < mine, dt <= delta,
-// newest Q per pixel, newest first) from LDS.  The spiral only decides ORDER and the 16-slot cut-off, so
-// it is applied afterwards: per-pixel candidate counts go to LDS indexed by spiral step, an exclusive
-// prefix over the steps gives every pixel its first slot, and a second pass over the (still staged)
-// entries places the sources.  ~3 memory round trips per lane instead of ~400 per wave.
-template <int R, int LPE, bool MARK>
-__global__ __launch_bounds__(64) void k_build_ell_rows(const int2* __restrict__ ev2, const int* __restrict__ key_s,
-                                                       const unsigned* __restrict__ start, const unsigned* flags_in, int N, int W,
-                                                       int H, int Q, int dt_max, int* __restrict__ ell_src,
-                                                       uint16_t* __restrict__ ell_step, int* __restrict__ deg,
-                                                       const int* __restrict__ node_slot, const int* __restrict__ node_vox,
-                                                       unsigned* __restrict__ bitmap, unsigned* flags) {
-    constexpr int D = 2 * R + 1, DD = D * D, EPW = 64 / LPE, SPL = (DD + LPE - 1) / LPE, STG = 8, MAXNB = 16;
-    __shared__ int s_cnt[EPW][DD];
-    __shared__ int2 s_ent[64][STG];
-    __shared__ int s_row[EPW][MAXNB];
-    __shared__ int s_stp[EPW][MAXNB];
-    const int lane = threadIdx.x, g = lane / LPE, sub = lane % LPE;
-    const int ev = blockIdx.x * EPW + g;
-    const bool active = ev < N;
-    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
-    for (int t = sub; t < DD; t += LPE) s_cnt[g][t] = 0;
-    if (sub < MAXNB / (LPE < MAXNB ? 1 : 1)) { for (int t = sub; t < MAXNB; t += LPE) { s_row[g][t] = 0; s_stp[g][t] = 0; } }
-    int me = 0, ts = 0, x = 0, y = 0, plane_base = 0;
-    if (active) {
-        const int k = key_s[ev];
-        const int2 mine = ev2[ev];
-        me = mine.x; ts = mine.y; x = k % W; y = (k / W) % H; plane_base = k - x - W * y;
-    }
-    // ---- this lane's window row: offsets and the first STG entries
-    const int j = sub, yy = y + j - R;
-    const bool row_ok = active && j < D && yy >= 0 && yy < H;
-    int stv[D + 1];
-#pragma unroll
-    for (int i = 0; i <= D; ++i) stv[i] = 0;
-    if (row_ok) {
-        const int rowb = plane_base + W * yy;
-#pragma unroll
-        for (int i = 0; i <= D; ++i) stv[i] = (int)start[rowb + min(max(x - R + i, 0), W)];
-    }
-    const int rs = stv[0], re = stv[D];
-    int stepv[D];                                            // spiral step of each pixel of this row (fetched together)
-#pragma unroll
-    for (int i = 0; i < D; ++i) stepv[i] = j < D ? c_stepof[j * D + i] : 0;
-#pragma unroll
-    for (int q = 0; q < STG; ++q) if (rs + q < re) s_ent[lane][q] = ev2[rs + q];
-    __syncthreads();
-    auto entry = [&](int s) -> int2 { return (s - rs < STG) ? s_ent[lane][s - rs] : ev2[s]; };
-    // ---- pass 1: number of valid sources per pixel of the row (capped at 15)
-    if (row_ok) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const int st = stv[i], en = stv[i + 1], lo = max(st, en - Q);
-            int c = 0;
-            for (int s = en - 1; s >= lo; --s) {
-                const int2 e = entry(s);
-                if (me > e.x) {
-                    if ((float)(ts - e.y) > (float)dt_max) { if (monotone) break; else continue; }
-                    if (++c >= MAXNB - 1) break;
-                }
-            }
-            s_cnt[g][stepv[i]] = c;
-        }
-    }
-    __syncthreads();
-    // ---- exclusive prefix over the spiral steps (each lane owns SPL consecutive steps)
-    int local = 0;
-#pragma unroll
-    for (int t = 0; t < SPL; ++t) { int q = sub * SPL + t; if (q < DD) local += s_cnt[g][q]; }
-    int incl = local;
-#pragma unroll
-    for (int d2 = 1; d2 < LPE; d2 <<= 1) { int v = __shfl_up(incl, d2, LPE); if (sub >= d2) incl += v; }
-    const int total = __shfl(incl, LPE - 1, LPE);
-    int run = incl - local;
-#pragma unroll
-    for (int t = 0; t < SPL; ++t) { int q = sub * SPL + t; if (q < DD) { int c = s_cnt[g][q]; s_cnt[g][q] = run; run += c; } }
-    __syncthreads();
-    // ---- pass 2: place the sources (slot 0 = self edge)
-    if (row_ok) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const int st = stv[i], en = stv[i + 1], lo = max(st, en - Q);
-            const int step = stepv[i];
-            const int off = 1 + s_cnt[g][step];
-            if (off >= MAXNB) continue;
-            int c = 0;
-            for (int s = en - 1; s >= lo; --s) {
-                const int2 e = entry(s);
-                if (me > e.x) {
-                    if ((float)(ts - e.y) > (float)dt_max) { if (monotone) break; else continue; }
-                    if (off + c < MAXNB) { s_row[g][off + c] = s; s_stp[g][off + c] = step; }
-                    if (++c >= MAXNB - 1 || off + c >= MAXNB) break;
-                }
-            }
-        }
-    }
-    if (active && sub == 0) s_row[g][0] = ev;
-    __syncthreads();
-    if (!active) return;
-    const int nn = min(MAXNB, 1 + total);
-    if (sub < 4) ((int4*)(ell_src + (size_t)ev * MAXNB))[sub] = make_int4(s_row[g][4 * sub], s_row[g][4 * sub + 1], s_row[g][4 * sub + 2], s_row[g][4 * sub + 3]);
-    if (sub < 2) {
-        const int* q = &s_stp[g][8 * sub];
-        ((uint4*)(ell_step + (size_t)ev * MAXNB))[sub] = make_uint4(q[0] | q[1] << 16, q[2] | q[3] << 16, q[4] | q[5] << 16, q[6] | q[7] << 16);
-    }
-    if (sub == 0) deg[ev] = nn;
-    if (MARK) {
-        const int my_slot = node_slot[ev], my_vox = node_vox[ev];
-        for (int e = 1 + sub; e < nn; e += LPE) evad_mark_edge_packed(node_vox[s_row[g][e]], my_vox, my_slot, bitmap, flags);
-    }
-}
-
-template <int R, int LPE>
-static void launch_rows(bool mark, int N, hipStream_t st, const int2* ev2, const int* key_s, const unsigned* start,
-                        const unsigned* counters, int W, int H, int Q, int dt, int* ell_src, uint16_t* ell_step, int* deg,
-                        const int* node_slot, const int* node_vox, unsigned* bitmap, unsigned* flags) {
-    dim3 grid(evad_blocks(N, 64 / LPE));
-    if (mark) hipLaunchKernelGGL((k_build_ell_rows<R, LPE, true>), grid, dim3(64), 0, st, ev2, key_s, start, counters, N, W, H, Q, dt,
-                                 ell_src, ell_step, deg, node_slot, node_vox, bitmap, flags);
-    else      hipLaunchKernelGGL((k_build_ell_rows<R, LPE, false>), grid, dim3(64), 0, st, ev2, key_s, start, counters, N, W, H, Q, dt,
-                                 ell_src, ell_step, deg, node_slot, node_vox, bitmap, flags);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Wave-per-event edge search: lanes = spiral steps.
-// With timestamps non-decreasing in id (checked on the device: EVAD_FLAG_T_NOT_MONOTONE) the valid
-// sources of one neighbour pixel are a CONTIGUOUS range of its id-sorted segment: ids below mine form a
-// prefix, entries inside the time window a suffix of that prefix, the FIFO depth another suffix.  A lane
-// therefore finds its pixel's range [lo, hi) with two binary searches (no data-dependent walk), a wave
-// scan over the 64 lanes turns the per-pixel counts into ELL slot offsets in spiral order, and each lane
-// writes its <= 15 sources newest first.  Radii beyond 3 (more than 64 steps) take further rounds of 64
-// steps and stop as soon as the row is full -- dense scenes finish in the first round.  No lane ever loops
-// over another lane's data, so the divergence cost of the thread-per-event walk (a wave paying the longest
-// FIFO walk of its lanes at each of (2R+1)^2 steps) disappears.
-// Non-monotone input falls back, per lane, to the reference's linear scan of the newest Q entries.
-template <bool MARK>
-__global__ __launch_bounds__(256) void k_build_ell_wave(const int2* __restrict__ ev2, const int* __restrict__ key_s,
-                                                        const unsigned* __restrict__ start, const unsigned* flags_in, int N, int W,
-                                                        int H, int steps, int Q, int dt_max, int* __restrict__ ell_src,
-                                                        uint16_t* __restrict__ ell_step, int* __restrict__ deg,
-                                                        const int* __restrict__ node_slot, const int* __restrict__ node_vox,
-                                                        unsigned* __restrict__ bitmap, unsigned* flags) {
-    constexpr int MAXNB = 16;
-    const int lane = threadIdx.x & 63;
-    const int ev = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ev >= N) return;
-    const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
-    const int k = key_s[ev];
-    const int2 mine = ev2[ev];
-    const int me = mine.x, ts = mine.y;
-    const int x = k % W, y = (k / W) % H, plane_base = k - x - W * y;
-    const int my_slot = MARK ? node_slot[ev] : 0, my_vox = MARK ? node_vox[ev] : 0;
-    int* row = ell_src + (size_t)ev * MAXNB;
-    uint16_t* srow = ell_step + (size_t)ev * MAXNB;
-    if (lane == 0) { row[0] = ev; srow[0] = 0; }
-    int filled = 1;                                          // wave-uniform: slots used so far
-    for (int i0 = 0; i0 < steps && filled < MAXNB; i0 += 64) {
-        const int i = i0 + lane;
-        int hi = 0, cnt = 0;
-        if (i < steps) {
-            const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
-            if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
-                const int p = plane_base + xn + W * yn;
-                const int st = (int)start[p], en = (int)start[p + 1];
-                const int lo0 = max(st, en - Q);             // the FIFO keeps the newest Q ids of the pixel
-                if (en > lo0) {
-                    if (monotone) {
-                        int a = lo0, b = en;                  // hi = first position with id >= mine
-                        while (a < b) { int m = (a + b) >> 1; if (ev2[m].x < me) a = m + 1; else b = m; }
-                        hi = a;
-                        a = lo0; b = hi;                      // lo = first position with ts - t <= dt_max
-                        while (a < b) { int m = (a + b) >> 1; if (ts - ev2[m].y > dt_max) a = m + 1; else b = m; }
-                        cnt = min(hi - a, MAXNB - 1);
-                    } else {                                  // exact reference scan (ev_graph.cu:51-76), count only
-                        for (int s = en - 1; s >= lo0 && cnt < MAXNB - 1; --s) {
-                            const int2 c = ev2[s];
-                            if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) ++cnt;
-                        }
-                        hi = en; cnt = cnt;
-                    }
-                }
-            }
-        }
-        int incl = cnt;                                       // inclusive scan over the lanes = spiral order
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-        const int total = __shfl(incl, 63, 64);
-        int slot = filled + incl - cnt;
-        if (cnt > 0 && slot < MAXNB) {
-            if (monotone) {
-                for (int j = 0; j < cnt && slot < MAXNB; ++j, ++slot) {
-                    const int sp = hi - 1 - j;
-                    row[slot] = sp; srow[slot] = (uint16_t)i;
-                    if (MARK) evad_mark_edge_packed(node_vox[sp], my_vox, my_slot, bitmap, flags);
-                }
-            } else {
-                const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
-                const int p = plane_base + xn + W * yn;
-                const int st = (int)start[p], en = (int)start[p + 1], lo0 = max(st, en - Q);
-                for (int s = en - 1; s >= lo0 && slot < MAXNB; --s) {
-                    const int2 c = ev2[s];
-                    if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) {
-                        row[slot] = s; srow[slot] = (uint16_t)i;
-                        if (MARK) evad_mark_edge_packed(node_vox[s], my_vox, my_slot, bitmap, flags);
-                        ++slot;
-                    }
-                }
-            }
-        }
-        filled = min(MAXNB, filled + total);
-    }
-    if (lane == 0) deg[ev] = filled;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Thread-per-event edge search without data-dependent inner loops.
-// PMC counters say every variant above spends ~200-300 VALU+SALU wave-instructions PER EVENT: the
-// thread-per-event walk because a wave executes, at each spiral step, the longest FIFO walk of its 64
-// lanes (divergence factor ~12), the wave- and row-parallel forms because most of their lanes sit on empty
-// pixels.  Here all 64 lanes of a wave stay converged: 8 spiral steps are processed together, the valid
-// source range [lo, hi) of each of their pixels is found by FIXED-trip binary searches (trip count =
-// bits of the longest pixel segment of the batch, measured by eventad_sort_events, capped by the FIFO
-// depth) whose loads are independent across the 8 steps, and only the final append of <= 15 sources into
-// the lane's LDS-staged ELL row is a (short) per-lane loop.  Requires timestamps non-decreasing in id
-// (contiguous valid ranges); otherwise the exact linear scan of the reference runs instead.
-#define BF_GROUP 8
-template <bool MARK>
-__global__ __launch_bounds__(256) void k_build_ell_bf(const int2* __restrict__ ev2, const int* __restrict__ key_s,
-                                                      const unsigned* __restrict__ start, const unsigned* flags_in, int N, int W,
-                                                      int H, int steps, int Q, int dt_max, int* __restrict__ ell_src,
-                                                      uint16_t* __restrict__ ell_step, int* __restrict__ deg,
-                                                      const int* __restrict__ node_slot, const int* __restrict__ node_vox,
-                                                      unsigned* __restrict__ bitmap, unsigned* flags) {
-    constexpr int MAXNB = 16;
-    __shared__ int s_row[256][MAXNB + 1];                    // +1: conflict-free per-lane rows
-    __shared__ unsigned short s_stp[256][MAXNB + 2];
-    const int tid = threadIdx.x;
-    const int r = blockIdx.x * 256 + tid;
-    const bool active = r < N;
-    const bool monotone = !(flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE);
-    const int lmax = min((int)flags_in[3], Q);
-    const int iters = 32 - __clz(max(lmax, 1));              // ceil(log2(lmax + 1))
-    int me = 0, ts = 0, x = 0, y = 0, plane_base = 0;
-    if (active) {
-        const int k = key_s[r];
-        const int2 mine = ev2[r];
-        me = mine.x; ts = mine.y; x = k % W; y = (k / W) % H; plane_base = k - x - W * y;
-    }
-#pragma unroll
-    for (int e = 0; e < MAXNB; ++e) { s_row[tid][e] = 0; s_stp[tid][e] = 0; }
-    s_row[tid][0] = r;
-    int nn = active ? 1 : MAXNB;                             // inactive lanes count as "full"
-    for (int i0 = 0; i0 < steps; i0 += BF_GROUP) {
-        if (__all(nn >= MAXNB)) break;                       // every lane of the wave is done
-        int st[BF_GROUP], en[BF_GROUP], a[BF_GROUP], b[BF_GROUP];
-#pragma unroll
-        for (int u = 0; u < BF_GROUP; ++u) {
-            st[u] = 0; en[u] = 0;
-            const int i = i0 + u;
-            if (i < steps && nn < MAXNB) {
-                const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
-                if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
-                    const int p = plane_base + xn + W * yn;
-                    st[u] = (int)start[p]; en[u] = (int)start[p + 1];
-                }
-            }
-        }
-        if (monotone) {
-            // two independent searches per pixel, in lockstep: a -> hi = first position with id >= mine,
-            // lo -> first position with ts - t <= dt_max (newer events have ts - t <= 0, so the predicate is
-            // monotone over the whole segment); valid sources are [lo, hi)
-            int lo[BF_GROUP], lb[BF_GROUP];
-#pragma unroll
-            for (int u = 0; u < BF_GROUP; ++u) { st[u] = max(st[u], en[u] - Q); a[u] = st[u]; b[u] = en[u]; lo[u] = st[u]; lb[u] = en[u]; }
-            for (int it = 0; it < iters; ++it) {
-#pragma unroll
-                for (int u = 0; u < BF_GROUP; ++u) {
-                    const int m = (a[u] + b[u]) >> 1, m2 = (lo[u] + lb[u]) >> 1;
-                    if (a[u] < b[u]) { if (ev2[m].x < me) a[u] = m + 1; else b[u] = m; }
-                    if (lo[u] < lb[u]) { if (ts - ev2[m2].y > dt_max) lo[u] = m2 + 1; else lb[u] = m2; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < BF_GROUP; ++u) {             // append hi-1 .. lo, newest first
-                const int cnt = a[u] - lo[u];
-                for (int j = 0; j < cnt && nn < MAXNB; ++j, ++nn) { s_row[tid][nn] = a[u] - 1 - j; s_stp[tid][nn] = (unsigned short)(i0 + u); }
-            }
-        } else {                                             // exact reference scan (ev_graph.cu:51-76)
-#pragma unroll
-            for (int u = 0; u < BF_GROUP; ++u) {
-                const int lo0 = max(st[u], en[u] - Q);
-                for (int sp = en[u] - 1; sp >= lo0 && nn < MAXNB; --sp) {
-                    const int2 c = ev2[sp];
-                    if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) { s_row[tid][nn] = sp; s_stp[tid][nn] = (unsigned short)(i0 + u); ++nn; }
-                }
-            }
-        }
-    }
-    if (!active) return;
-    int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rp[q] = make_int4(s_row[tid][4 * q], s_row[tid][4 * q + 1], s_row[tid][4 * q + 2], s_row[tid][4 * q + 3]);
-    uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const unsigned short* c = &s_stp[tid][8 * q];
-        sp4[q] = make_uint4(c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16, c[6] | c[7] << 16);
-    }
-    deg[r] = nn;
-    if (MARK) {
-        const int my_slot = node_slot[r], my_vox = node_vox[r];
-        int vs[MAXNB];
-#pragma unroll
-        for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[s_row[tid][e]] : my_vox;
-#pragma unroll
-        for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Same converged-lane search, with the pixel table and the FIFO entries of a row strip (+ halo) staged in
-// LDS.  The global-memory form above is bound by the CU's vector-memory issue rate (~560 wave-level loads
-// per 64 events, each occupying the texture-address path for ~16 cycles); here one workgroup owns R pixel
-// rows of one clip, stages start[] of rows [y0-rad, y0+R+rad) and the (contiguous, pixel-sorted) events of
-// those rows once with coalesced loads, and the searches read LDS.  Events that do not fit the staged
-// window (CAP) are read from global memory, so dense strips stay correct.
-template <bool MARK>
-__global__ __launch_bounds__(256) void k_build_ell_tile(const int2* __restrict__ ev2, const int* __restrict__ key_s,
-                                                        const unsigned* __restrict__ start, const unsigned* flags_in, int W, int H,
-                                                        int R, int rad, int steps, int Q, int dt_max, int TBL, int CAP,
-                                                        int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
-                                                        int* __restrict__ deg, const int* __restrict__ node_slot,
-                                                        const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
-                                                        unsigned* flags) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
-    constexpr int MAXNB = 16, RS = MAXNB + 1, SS = MAXNB + 2;
-    int* s_start = s_dyn;                                    // [TBL]
-    int2* s_ev = (int2*)(s_dyn + TBL);                       // [CAP]
-    int* s_row = (int*)(s_ev + CAP);                         // [256][17]
-    unsigned short* s_stp = (unsigned short*)(s_row + 256 * RS);   // [256][18]
-    const int tid = threadIdx.x;
-    const int strips = (H + R - 1) / R;
-    const int b = blockIdx.x / strips, y0 = (blockIdx.x % strips) * R;
-    const int ylo = max(y0 - rad, 0), yhi = min(y0 + R + rad, H);
-    const int plane_base = b * W * H, p_lo = plane_base + ylo * W, nt = (yhi - ylo) * W + 1;
-    for (int i = tid; i < nt; i += 256) s_start[i] = (int)start[p_lo + i];
-    __syncthreads();
-    const int ev_lo = s_start[0], nstage = min(s_start[nt - 1] - ev_lo, CAP);
-    for (int i = tid; i < nstage; i += 256) s_ev[i] = ev2[ev_lo + i];
-    __syncthreads();
-    const bool monotone = !(flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE);
-    const int lmax = min((int)flags_in[3], Q);
-    const int iters = 32 - __clz(max(lmax, 1));
-    const int my_lo = s_start[(y0 - ylo) * W], my_hi = s_start[(min(y0 + R, H) - ylo) * W];
-    auto fetch = [&](int m) -> int2 { const int o = m - ev_lo; return o < CAP ? s_ev[o] : ev2[m]; };
-    int* row = s_row + tid * RS;
-    unsigned short* stp = s_stp + tid * SS;
-    for (int base = my_lo; base < my_hi; base += 256) {
-        const int r = base + tid;
-        const bool active = r < my_hi;
-        int me = 0, ts = 0, x = 0, y = 0;
-        if (active) {
-            const int k = key_s[r];
-            const int2 mine = fetch(r);
-            me = mine.x; ts = mine.y; x = k % W; y = (k / W) % H;
-        }
-#pragma unroll
-        for (int e = 0; e < MAXNB; ++e) { row[e] = 0; stp[e] = 0; }
-        row[0] = r;
-        int nn = active ? 1 : MAXNB;
-        for (int i0 = 0; i0 < steps; i0 += BF_GROUP) {
-            if (__all(nn >= MAXNB)) break;
-            int st[BF_GROUP], en[BF_GROUP], a[BF_GROUP], b2[BF_GROUP];
-#pragma unroll
-            for (int u = 0; u < BF_GROUP; ++u) {
-                st[u] = 0; en[u] = 0;
-                const int i = i0 + u;
-                if (i < steps && nn < MAXNB) {
-                    const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
-                    if (xn >= 0 && yn >= 0 && xn < W && yn < H) {
-                        const int idx = (yn - ylo) * W + xn;
-                        st[u] = s_start[idx]; en[u] = s_start[idx + 1];
-                    }
-                }
-            }
-            if (monotone) {
-                int lo[BF_GROUP], lb[BF_GROUP];
-#pragma unroll
-                for (int u = 0; u < BF_GROUP; ++u) { st[u] = max(st[u], en[u] - Q); a[u] = st[u]; b2[u] = en[u]; lo[u] = st[u]; lb[u] = en[u]; }
-                for (int it = 0; it < iters; ++it) {
-#pragma unroll
-                    for (int u = 0; u < BF_GROUP; ++u) {
-                        const int m = (a[u] + b2[u]) >> 1, m2 = (lo[u] + lb[u]) >> 1;
-                        if (a[u] < b2[u]) { if (fetch(m).x < me) a[u] = m + 1; else b2[u] = m; }
-                        if (lo[u] < lb[u]) { if (ts - fetch(m2).y > dt_max) lo[u] = m2 + 1; else lb[u] = m2; }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < BF_GROUP; ++u) {
-                    const int cnt = a[u] - lo[u];
-                    for (int j = 0; j < cnt && nn < MAXNB; ++j, ++nn) { row[nn] = a[u] - 1 - j; stp[nn] = (unsigned short)(i0 + u); }
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < BF_GROUP; ++u) {
-                    const int lo0 = max(st[u], en[u] - Q);
-                    for (int sp = en[u] - 1; sp >= lo0 && nn < MAXNB; --sp) {
-                        const int2 c = fetch(sp);
-                        if (me > c.x && !((float)(ts - c.y) > (float)dt_max)) { row[nn] = sp; stp[nn] = (unsigned short)(i0 + u); ++nn; }
-                    }
-                }
-            }
-        }
-        if (active) {
-            int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rp[q] = make_int4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
-            uint4* sp4 = (uint4*)(ell_step + (size_t)r * MAXNB);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const unsigned short* c = stp + 8 * q;
-                sp4[q] = make_uint4(c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16, c[6] | c[7] << 16);
-            }
-            deg[r] = nn;
-            if (MARK) {
-                const int my_slot = node_slot[r], my_vox = node_vox[r];
-                int vs[MAXNB];
-#pragma unroll
-                for (int e = 1; e < MAXNB; ++e) vs[e] = e < nn ? node_vox[row[e]] : my_vox;
-#pragma unroll
-                for (int e = 1; e < MAXNB; ++e) if (e < nn) evad_mark_edge_packed(vs[e], my_vox, my_slot, bitmap, flags);
-            }
-        }
-    }
-}
-
-// LDS plan of k_build_ell_tile: rows per workgroup, table length, staged-event capacity; false = does not fit
-static bool tile_plan(int B, int W, int H, int rad, int* R, int* TBL, int* CAP, size_t* lds) {
-    const int rows_bytes = 256 * (17 * 4 + 18 * 2);
-    int r = (int)(((long long)B * H) / 512);
-    r = r < 1 ? 1 : (r > 8 ? 8 : r);
-    for (; r >= 1; r >>= 1) {
-        int tbl = (((r + 2 * rad) * W + 1) + 3) & ~3;
-        long long left = 64 * 1024 - rows_bytes - (long long)tbl * 4;
-        if (left >= 512 * 8) { *R = r; *TBL = tbl; *CAP = (int)(left / 8); *lds = (size_t)tbl * 4 + (size_t)*CAP * 8 + rows_bytes; return true; }
-    }
-    return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1292,7 +668,7 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
                                  const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
                                  int32_t* deg, const int32_t* node_slot, const int32_t* node_vox, int nx, int ny,
-                                 uint32_t* bitmap, int strip_width, int bitmap_prezeroed, void* stream) {
+                                 uint32_t* bitmap, int variant, int bitmap_prezeroed, void* stream) {
     if (!sid || !ts_s || !key_s || !pix_start || !counters || !ell_src || !ell_step || !deg || N < 0 || B <= 0 ||
         W <= 0 || H <= 0 || radius_px < 0 || max_num_neighbors < 1 || max_num_neighbors > 65535 || queue_size < 1 ||
         (bitmap && (!node_slot || !node_vox || nx <= 0 || ny <= 0 || nx > 255 || ny > 255)))
@@ -1303,69 +679,25 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
     int steps;
     if (ensure_spiral(radius_px, st, &steps)) return -2;
     if (steps > 65535) return EVAD_ERR_ARG;
-    int tR = 0, tTBL = 0, tCAP = 0; size_t tlds = 0;
-    if (max_num_neighbors == 16 && ev2 && strip_width == -6 && (radius_px == 1 || radius_px == 3)) {
-        dim3 grid(evad_blocks(N, 256));
+    const bool fast = max_num_neighbors == 16 && ev2 && radius_px <= SPIRAL_MAX_R;
+    dim3 grid(evad_blocks(N, 256));
+    if (fast && variant == 1 && (radius_px == 1 || radius_px == 3)) {
 #define EVAD_RS(RR, MK) hipLaunchKernelGGL((k_build_ell_rowscan<RR, MK>), grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, \
                                             N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters)
         if (radius_px == 1) { if (bitmap) EVAD_RS(1, true); else EVAD_RS(1, false); }
         else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
 #undef EVAD_RS
-        return evad_last_error();
-    }
-    if (max_num_neighbors == 16 && ev2 && strip_width == -5 && radius_px <= SPIRAL_MAX_R && tile_plan(B, W, H, radius_px, &tR, &tTBL, &tCAP, &tlds)) {
-        dim3 grid((unsigned)(B * ((H + tR - 1) / tR)));
-        if (bitmap) hipLaunchKernelGGL(k_build_ell_tile<true>, grid, dim3(256), tlds, st, (const int2*)ev2, key_s, pix_start, counters, W, H, tR,
-                                       radius_px, steps, queue_size, delta_t_us, tTBL, tCAP, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-        else        hipLaunchKernelGGL(k_build_ell_tile<false>, grid, dim3(256), tlds, st, (const int2*)ev2, key_s, pix_start, counters, W, H, tR,
-                                       radius_px, steps, queue_size, delta_t_us, tTBL, tCAP, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-    } else if (max_num_neighbors == 16 && ev2 && (strip_width == -4 || strip_width == -5) && radius_px <= SPIRAL_MAX_R) {
-        dim3 grid(evad_blocks(N, 256));
-        if (bitmap) hipLaunchKernelGGL(k_build_ell_bf<true>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
-                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-        else        hipLaunchKernelGGL(k_build_ell_bf<false>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
-                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-    } else if (max_num_neighbors == 16 && ev2 && strip_width == -3 && radius_px <= SPIRAL_MAX_R) {
-        dim3 grid(evad_blocks(N, 4));
-        if (bitmap) hipLaunchKernelGGL(k_build_ell_wave<true>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
-                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-        else        hipLaunchKernelGGL(k_build_ell_wave<false>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
-                                       steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-    } else if (max_num_neighbors == 16 && ev2 && strip_width == -2 && (radius_px == 1 || radius_px == 3 || radius_px == 7 || radius_px == 13)) {
-        const int2* e2 = (const int2*)ev2;
-        if (radius_px == 1)       launch_rows<1, 4>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-        else if (radius_px == 3)  launch_rows<3, 8>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-        else if (radius_px == 7)  launch_rows<7, 16>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-        else                      launch_rows<13, 32>(bitmap != nullptr, N, st, e2, key_s, pix_start, counters, W, H, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-    } else if (max_num_neighbors == 16 && ev2 && strip_width > 0 && radius_px <= SPIRAL_MAX_R) {
-        int R = radius_px, D = 2 * R + 1, cols = strip_width + 2 * R + 1;
-        size_t lds = sizeof(int) * ((size_t)D * cols + ((D + 1 + 3) & ~3)) + sizeof(int2) * ELL_CAP + (bitmap ? sizeof(int) * ELL_CAP : 0);
-        if (lds > 60 * 1024) return EVAD_ERR_ARG;
-        dim3 grid((unsigned)((long long)B * H * ((W + strip_width - 1) / strip_width)));
+    } else if (fast) {
         if (bitmap)
-            hipLaunchKernelGGL(k_build_ell_strip<true>, grid, dim3(64), lds, st, (const int2*)ev2, key_s, pix_start, g_spiral_dev,
-                               counters, W, H, R, strip_width, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
-                               node_vox, bitmap, counters);
-        else
-            hipLaunchKernelGGL(k_build_ell_strip<false>, grid, dim3(64), lds, st, (const int2*)ev2, key_s, pix_start, g_spiral_dev,
-                               counters, W, H, R, strip_width, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
-                               node_vox, bitmap, counters);
-    } else if (max_num_neighbors == 16 && ev2 && strip_width < 0 && radius_px <= SPIRAL_MAX_R) {   // -1, or -2 with an unsupported radius
-        if (bitmap)
-            hipLaunchKernelGGL(k_build_ell_reg<true>, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
+            hipLaunchKernelGGL(k_build_ell_reg<true>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
                                counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
         else
-            hipLaunchKernelGGL(k_build_ell_reg<false>, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
+            hipLaunchKernelGGL(k_build_ell_reg<false>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
                                counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-    }
-    else if (max_num_neighbors == 16 && ev2)
-        hipLaunchKernelGGL(k_build_ell_g, dim3(evad_blocks(N, 256)), dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
-                           g_spiral_dev, counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot,
-                           node_vox, bitmap, counters);
-    else {
-        if (bitmap) return EVAD_ERR_ARG;                     // fused marking only exists in the batched kernel
-        hipLaunchKernelGGL(k_build_ell, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid, ts_s, key_s, pix_start, g_spiral_dev,
-                           counters, N, W, H, steps, queue_size, delta_t_us, max_num_neighbors, ell_src, ell_step, deg);
+    } else {                                                 // any neighbour cap / radius: the reference-style walk
+        if (bitmap) return EVAD_ERR_ARG;                     // (mark with eventad_pool_edges_mark_ell afterwards)
+        hipLaunchKernelGGL(k_build_ell, grid, dim3(256), 0, st, sid, ts_s, key_s, pix_start, g_spiral_dev, counters, N, W, H,
+                           steps, queue_size, delta_t_us, max_num_neighbors, ell_src, ell_step, deg);
     }
     return evad_last_error();
 }

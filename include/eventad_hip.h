@@ -74,15 +74,15 @@ int eventad_sort_events(const float* pos, const int64_t* batch, const float* pol
  * pixel-sorted numbering: ell_src i32[N,K] (slot 0 = self edge), ell_step u16[N,K] (spiral step =
  * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
  * the source-voxel bit in the destination voxel's pool1 neighbour bitmap u32[S,3] (= eventad_pool_edges_mark_ell).
- * strip_width (needs ev2): > 0 LDS-staged search, one wave per strip of that many pixels of a sensor row;
- * 0 batched prefetch; -1 thread per event, row in registers (default); -2 row-parallel; -3 wave per event with
- * binary-searched ranges; -4 converged lanes with fixed-trip binary searches; -5 the same over LDS-staged row
- * strips; -6 row scan (radius 1 or 3; 2R+1 contiguous range look-ups per event instead of (2R+1)^2 pixel probes, the
- * fastest for sparse windows).  All variants give identical rows.  bitmap_prezeroed != 0: the caller already cleared the bitmap. */
+ * variant (needs ev2 and max_num_neighbors == 16, else the reference-style walk runs and bitmap must be NULL):
+ * 0 = thread per event walking the spiral with the row in registers and an early exit after 16 neighbours (dense
+ * windows); 1 = row scan, radius 1 or 3 only (2R+1 contiguous range look-ups per event instead of (2R+1)^2 pixel
+ * probes, candidates fetched 8 at a time -- sparse windows; other radii fall back to 0).  Identical rows either way.
+ * bitmap_prezeroed != 0: the caller already cleared the bitmap. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                       int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step, int32_t* deg,
-                      const int32_t* node_slot, const int32_t* node_vox, int nx, int ny, uint32_t* bitmap, int strip_width,
+                      const int32_t* node_slot, const int32_t* node_vox, int nx, int ny, uint32_t* bitmap, int variant,
                       int bitmap_prezeroed, void* stream);
 /* ELL -> the reference's edge buffer layout (i64[2,K], event numbering, -1 padded). */
 int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32_t* sid, int N, int max_num_neighbors,

@@ -44,43 +44,13 @@ def ell_old():
 
 
 print("N", N, "E", int(ws["deg"].sum()), "max deg", int(ws["deg"].max()), "deg==16 frac", float((ws["deg"] == 16).float().mean()))
-print("build_ell batched + mark : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap))))
-print("build_ell batched no mark: %.1f us" % timeit(lambda: ell(None)))
 print("build_ell reference-style: %.1f us" % timeit(ell_old))
 ref_src, ref_deg = ws["ell_src"].clone(), ws["deg"].clone()
-t = timeit(lambda: ell(None, -1))
-ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
-print("build_ell register rows  : %.1f us  (matches %s)" % (t, ok))
-print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -1)))
-t = timeit(lambda: ell(None, -4))
-ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
-print("build_ell converged lanes: %.1f us  (matches %s)  lmax %d" % (t, ok, int(ws["counters"][3])))
-print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -4)))
-t = timeit(lambda: ell(None, -6))
-ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
-print("build_ell row scan       : %.1f us  (matches %s)" % (t, ok))
-print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -6)))
-t = timeit(lambda: ell(None, -5))
-ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
-print("build_ell LDS row tiles  : %.1f us  (matches %s)" % (t, ok))
-print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -5)))
-t = timeit(lambda: ell(None, -3))
-ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
-print("build_ell wave-per-event : %.1f us  (matches %s)" % (t, ok))
-print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -3)))
-t = timeit(lambda: ell(None, -2))
-ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
-print("build_ell row-parallel   : %.1f us  (matches %s)" % (t, ok))
-print("           + fused mark  : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), -2)))
-for sw in (16, 32, 64, 128):
-    t = timeit(lambda: ell(None, sw))
-    ok = torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
-    print("build_ell LDS strip SW=%3d : %.1f us  (matches %s)" % (sw, t, ok))
-    print("           + fused mark   : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), sw)))
+same = lambda: torch.equal(ws["deg"], ref_deg) and bool((torch.where(torch.arange(16, device=dev).view(1, -1) < ref_deg.view(-1, 1), ws["ell_src"] - ref_src, 0) == 0).all())
+for name, v in (("register rows (spiral)", 0), ("row scan", 1)):
+    t = timeit(lambda: ell(None, v))
+    print("build_ell %-22s: %.1f us  (matches %s)  longest segment %d" % (name, t, same(), int(ws["counters"][3])))
+    print("           + fused mark           : %.1f us" % timeit(lambda: ell(ptr(ws["levels"][0].bitmap), v)))
 L = ws["levels"][0]
-print("mark_ell separate        : %.1f us" % timeit(lambda: call("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]),
+print("mark_ell separate                : %.1f us" % timeit(lambda: call("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]),
       ptr(ws["node_slot0"]), N, 16, L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["counters"]), st)))
-x = torch.empty(N * 16, dtype=torch.int32, device=dev)
-print("memset 25.6MB (N*16*4)    : %.1f us" % timeit(lambda: x.zero_()))
-y = torch.empty_like(x)
-print("copy 25.6MB               : %.1f us" % timeit(lambda: y.copy_(x)))
