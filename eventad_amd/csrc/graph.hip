@@ -249,10 +249,6 @@ int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, 
     return evad_exclusive_scan_max(in, out, tile_sums, n, nullptr, st);
 }
 
-extern "C" int eventad_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, int64_t n, void* stream) {
-    if (!in || !out || !tile_sums || n < 0) return EVAD_ERR_ARG;
-    return evad_exclusive_scan(in, out, tile_sums, n, (hipStream_t)stream);
-}
 
 // =============================================================================================
 // (B) native path: counting sort by pixel + ELL edge search

@@ -65,268 +65,12 @@ extern "C" int eventad_head_tables(const float* bbox, const int64_t* bbox_batch,
 }
 
 // ------------------------------------------------------------------------------------------------
-// GRU cell (PyTorch gate order r,z,n): h' = (1-z)*n + z*h,  n = tanh(gi_n + r*gh_n).
-// gates_out keeps (r,z,n) for the backward pass; xdrop = h' * mask is the dropout'd input of the
-// next GRU layer (nn.GRU(dropout=0.3), EventAD.py:86).
-__global__ void k_gru_cell_fwd(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hprev,
-                               int rows, int H, float* __restrict__ gates, float* __restrict__ hnew,
-                               const float* __restrict__ mask, float* __restrict__ xdrop) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= rows * H) return;
-    int row = t / H, j = t % H;
-    const float* a = gi + (size_t)row * 3 * H; const float* c = gh + (size_t)row * 3 * H;
-    float r = sigmoidf_(a[j] + c[j]);
-    float z = sigmoidf_(a[H + j] + c[H + j]);
-    float n = tanhf_(a[2 * H + j] + r * c[2 * H + j]);
-    float h = hprev[t];
-    float hn = (1.f - z) * n + z * h;
-    float* g = gates + (size_t)row * 3 * H;
-    g[j] = r; g[H + j] = z; g[2 * H + j] = n;
-    hnew[t] = hn;
-    if (xdrop) xdrop[t] = mask ? hn * mask[t] : hn;
-}
-
-extern "C" int eventad_gru_cell_fwd(const float* gi, const float* gh, const float* hprev, int rows, int H, float* gates,
-                                    float* hnew, const float* mask, float* xdrop, void* stream) {
-    if (!gi || !gh || !hprev || !gates || !hnew || rows <= 0 || H <= 0) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_gru_cell_fwd, dim3(evad_blocks((long long)rows * H, 256)), dim3(256), 0, (hipStream_t)stream, gi, gh,
-                       hprev, rows, H, gates, hnew, mask, xdrop);
-    return evad_last_error();
-}
-
-struct CellProb { const float* a; const float* b; const float* c; const float* d; const float* e; const float* f;
-                  const float* g2; float* o0; float* o1; float* o2; int H; };
-struct CellGroup { CellProb p[3]; int n; };
-
-__global__ void k_gru_cell_fwd_g(CellGroup g) {
-    const CellProb& P = g.p[blockIdx.y];
-    int t = blockIdx.x * blockDim.x + threadIdx.x, H = P.H;
-    if (t >= NT * H) return;
-    int row = t / H, j = t % H;
-    const float* a = P.a + (size_t)row * 3 * H; const float* c = P.b + (size_t)row * 3 * H;        // gi, gh
-    float r = sigmoidf_(a[j] + c[j]);
-    float z = sigmoidf_(a[H + j] + c[H + j]);
-    float n = tanhf_(a[2 * H + j] + r * c[2 * H + j]);
-    float h = P.c[t];                                                                               // hprev
-    float hn = (1.f - z) * n + z * h;
-    float* gt = P.o0 + (size_t)row * 3 * H;                                                         // gates
-    gt[j] = r; gt[H + j] = z; gt[2 * H + j] = n;
-    P.o1[t] = hn;                                                                                   // hnew
-    if (P.o2) P.o2[t] = P.d ? hn * P.d[t] : hn;                                                     // xdrop, mask
-}
-
-__global__ void k_gru_cell_bwd_g(CellGroup g) {
-    const CellProb& P = g.p[blockIdx.y];
-    int t = blockIdx.x * blockDim.x + threadIdx.x, H = P.H;
-    if (t >= NT * H) return;
-    int row = t / H, j = t % H;
-    float dh = P.a[t];                                                                              // dhn
-    if (P.b) dh += P.c ? P.b[t] * P.c[t] : P.b[t];                                                  // dx_extra, mask
-    const float* gt = P.d + (size_t)row * 3 * H;                                                    // gates
-    float r = gt[j], z = gt[H + j], n = gt[2 * H + j];
-    float ghn = P.e[(size_t)row * 3 * H + 2 * H + j];                                               // gh
-    float h = P.f[t];                                                                               // hprev
-    float dn = dh * (1.f - z), dz = dh * (h - n);
-    float dan = dn * (1.f - n * n), daz = dz * z * (1.f - z), dar = dan * ghn * r * (1.f - r);
-    float* a = P.o0 + (size_t)row * 3 * H; float* c = P.o1 + (size_t)row * 3 * H;                  // dgi, dgh
-    a[j] = dar; a[H + j] = daz; a[2 * H + j] = dan;
-    c[j] = dar; c[H + j] = daz; c[2 * H + j] = dan * r;
-    P.o2[t] = P.g2[t] + dh * z;                                                                     // dsprev = dspass + dh*z
-}
-
-extern "C" int eventad_gru_cell_fwd_group(int n, const int64_t* desc, void* stream) {
-    if (n < 1 || n > 3 || !desc) return EVAD_ERR_ARG;
-    CellGroup g; g.n = n; int hmax = 0;
-    for (int i = 0; i < n; ++i) {
-        const int64_t* q = desc + 12 * i; CellProb& P = g.p[i];
-        P.a = (const float*)q[0]; P.b = (const float*)q[1]; P.c = (const float*)q[2]; P.o0 = (float*)q[3]; P.o1 = (float*)q[4];
-        P.d = (const float*)q[5]; P.o2 = (float*)q[6]; P.H = (int)q[7];
-        if (!P.a || !P.b || !P.c || !P.o0 || !P.o1 || P.H <= 0) return EVAD_ERR_ARG;
-        if (P.H > hmax) hmax = P.H;
-    }
-    hipLaunchKernelGGL(k_gru_cell_fwd_g, dim3(evad_blocks(NT * hmax, 256), n), dim3(256), 0, (hipStream_t)stream, g);
-    return evad_last_error();
-}
-
-extern "C" int eventad_gru_cell_bwd_group(int n, const int64_t* desc, void* stream) {
-    if (n < 1 || n > 3 || !desc) return EVAD_ERR_ARG;
-    CellGroup g; g.n = n; int hmax = 0;
-    for (int i = 0; i < n; ++i) {
-        const int64_t* q = desc + 12 * i; CellProb& P = g.p[i];
-        P.a = (const float*)q[0]; P.b = (const float*)q[1]; P.c = (const float*)q[2]; P.d = (const float*)q[3];
-        P.e = (const float*)q[4]; P.f = (const float*)q[5]; P.g2 = (const float*)q[6]; P.o0 = (float*)q[7];
-        P.o1 = (float*)q[8]; P.o2 = (float*)q[9]; P.H = (int)q[10];
-        if (!P.a || !P.d || !P.e || !P.f || !P.g2 || !P.o0 || !P.o1 || !P.o2 || P.H <= 0) return EVAD_ERR_ARG;
-        if (P.H > hmax) hmax = P.H;
-    }
-    hipLaunchKernelGGL(k_gru_cell_bwd_g, dim3(evad_blocks(NT * hmax, 256), n), dim3(256), 0, (hipStream_t)stream, g);
-    return evad_last_error();
-}
-
-// dh = dHn (+ dx_extra*mask);  dn = dh*(1-z), dz = dh*(h-n), dh_prev = dSpass + dh*z;
-// dgi = (da_r, da_z, da_n), dgh = (da_r, da_z, da_n*r)  with da_n = dn*(1-n^2), da_z = dz*z(1-z),
-// da_r = da_n*gh_n*r(1-r).
-__global__ void k_gru_cell_bwd(const float* __restrict__ dhn, const float* __restrict__ dx_extra,
-                               const float* __restrict__ mask, const float* __restrict__ gates, const float* __restrict__ gh,
-                               const float* __restrict__ hprev, const float* __restrict__ dspass, int rows, int H,
-                               float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dsprev) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= rows * H) return;
-    int row = t / H, j = t % H;
-    float dh = dhn[t];
-    if (dx_extra) dh += mask ? dx_extra[t] * mask[t] : dx_extra[t];
-    const float* g = gates + (size_t)row * 3 * H;
-    float r = g[j], z = g[H + j], n = g[2 * H + j];
-    float ghn = gh[(size_t)row * 3 * H + 2 * H + j];
-    float h = hprev[t];
-    float dn = dh * (1.f - z), dz = dh * (h - n);
-    float dan = dn * (1.f - n * n);
-    float daz = dz * z * (1.f - z);
-    float dar = dan * ghn * r * (1.f - r);
-    float* a = dgi + (size_t)row * 3 * H; float* c = dgh + (size_t)row * 3 * H;
-    a[j] = dar; a[H + j] = daz; a[2 * H + j] = dan;
-    c[j] = dar; c[H + j] = daz; c[2 * H + j] = dan * r;
-    dsprev[t] = dspass[t] + dh * z;
-}
-
-extern "C" int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* mask, const float* gates,
-                                    const float* gh, const float* hprev, const float* dspass, int rows, int H,
-                                    float* dgi, float* dgh, float* dsprev, void* stream) {
-    if (!dhn || !gates || !gh || !hprev || !dspass || !dgi || !dgh || !dsprev || rows <= 0 || H <= 0) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_gru_cell_bwd, dim3(evad_blocks((long long)rows * H, 256)), dim3(256), 0, (hipStream_t)stream, dhn,
-                       dx_extra, mask, gates, gh, hprev, dspass, rows, H, dgi, dgh, dsprev);
-    return evad_last_error();
-}
-
-// ------------------------------------------------------------------------------------------------
-// SpatialAttention (EventAD.py:100-138) over the valid tracks of one clip; up to 3 independent
-// problems (event GRU layer 0, layer 1, coordinate GRU) per launch, one workgroup each:
-//   s_k = tanh(Hn_k).w ; alpha = softmax_valid(s) ; S'_k = valid ? Hn_k*alpha_k : S_k (state kept)
-struct AttProb { const float* Hn; const float* Sprev; const float* w; float* alpha; float* Snext;
-                 const float* dSnext; const float* dHn_out; float* dHn; float* dSpass; float* dw; int H; };
-struct AttGroup { AttProb p[3]; const int* valid; int n; };
-
-__device__ __forceinline__ float wave_sum(float v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
-__device__ __forceinline__ float wave_max(float v) { for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64)); return v; }
-
-// Mapping: thread = (track row k = tid>>3, column chunk c = tid&7); a thread owns H/8 consecutive hidden
-// columns of its row, so every row dot product is H/8 independent loads + FMAs in registers followed by
-// a 3-step reduction over 8 neighbouring lanes (no long shuffle chains, no serial row passes).
-template <int CH>
-__device__ __forceinline__ void att_fwd_body(const AttProb& P, const int* valid) {
-    __shared__ float s_s[NT];
-    __shared__ int s_v[NT];
-    const int tid = threadIdx.x, k = tid >> 3, c = tid & 7, H = CH * 8;
-    if (tid < NT) s_v[tid] = valid[tid];
-    const size_t base = (size_t)k * H + c * CH;
-    float hn[CH];
-    float part = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) hn[i] = P.Hn[base + i];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) part += tanhf_(hn[i]) * P.w[c * CH + i];
-    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-    if (c == 0) s_s[k] = part;
-    __syncthreads();
-    float m = -3.4e38f;
-#pragma unroll
-    for (int q = 0; q < NT; ++q) if (s_v[q]) m = fmaxf(m, s_s[q]);
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < NT; ++q) if (s_v[q]) sum += expf(s_s[q] - m);
-    const bool v = s_v[k] != 0;
-    const float a = v ? expf(s_s[k] - m) / sum : 0.f;
-    if (c == 0) P.alpha[k] = a;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) P.Snext[base + i] = v ? hn[i] * a : P.Sprev[base + i];
-}
-
-__global__ __launch_bounds__(256) void k_att_fwd(AttGroup g) {
-    const AttProb& P = g.p[blockIdx.x];
-    if (P.H == 256) att_fwd_body<32>(P, g.valid); else att_fwd_body<4>(P, g.valid);
-}
-
-// backward: dHn (total, incl. dHn_out from the fusion / next-layer branch), dSpass (rows whose state was
-// kept), dw += this clip's contribution (fixed summation order inside one workgroup).
-template <int CH>
-__device__ __forceinline__ void att_bwd_body(const AttProb& P, const int* valid) {
-    constexpr int H = CH * 8;
-    __shared__ float s_da[NT], s_al[NT], s_c[NT][H + 1];
-    __shared__ int s_v[NT];
-    const int tid = threadIdx.x, k = tid >> 3, c = tid & 7;
-    if (tid < NT) { s_v[tid] = valid[tid]; s_al[tid] = P.alpha[tid]; }
-    const size_t base = (size_t)k * H + c * CH;
-    float hn[CH], gs[CH];
-    float part = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) { hn[i] = P.Hn[base + i]; gs[i] = P.dSnext[base + i]; }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) part += gs[i] * hn[i];
-    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-    __syncthreads();
-    if (c == 0) s_da[k] = s_v[k] ? part : 0.f;
-    __syncthreads();
-    float dot = 0.f;
-#pragma unroll
-    for (int q = 0; q < NT; ++q) if (s_v[q]) dot += s_al[q] * s_da[q];
-    const bool v = s_v[k] != 0;
-    const float al = s_al[k], ds = v ? al * (s_da[k] - dot) : 0.f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        float th = tanhf_(hn[i]);
-        if (v) {
-            float d = gs[i] * al + ds * P.w[c * CH + i] * (1.f - th * th);
-            if (P.dHn_out) d += P.dHn_out[base + i];
-            P.dHn[base + i] = d; P.dSpass[base + i] = 0.f;
-        } else { P.dHn[base + i] = 0.f; P.dSpass[base + i] = gs[i]; }
-        s_c[k][c * CH + i] = ds * th;
-    }
-    __syncthreads();
-    for (int j = tid; j < H; j += 256) {
-        float acc = 0.f;
-#pragma unroll
-        for (int q = 0; q < NT; ++q) acc += s_c[q][j];
-        P.dw[j] += acc;                                     // every problem of a launch owns its own dw accumulator
-    }
-}
-
-__global__ __launch_bounds__(256) void k_att_bwd(AttGroup g) {
-    const AttProb& P = g.p[blockIdx.x];
-    if (P.H == 256) att_bwd_body<32>(P, g.valid); else att_bwd_body<4>(P, g.valid);
-}
-
-/* desc: HOST array, 12 int64 per problem: [0] Hn [1] Sprev [2] w [3] alpha [4] Snext [5] dSnext [6] dHn_out
- * [7] dHn [8] dSpass [9] dw [10] H.  fwd uses 0-4,10; bwd uses 0,2,3,5-10. */
-static int att_group(int n, const int64_t* d, const int32_t* valid, AttGroup* g) {
-    if (n < 1 || n > 3 || !d || !valid) return EVAD_ERR_ARG;
-    g->n = n; g->valid = valid;
-    for (int i = 0; i < n; ++i) {
-        const int64_t* q = d + 12 * i;
-        AttProb& P = g->p[i];
-        P.Hn = (const float*)q[0]; P.Sprev = (const float*)q[1]; P.w = (const float*)q[2]; P.alpha = (float*)q[3];
-        P.Snext = (float*)q[4]; P.dSnext = (const float*)q[5]; P.dHn_out = (const float*)q[6]; P.dHn = (float*)q[7];
-        P.dSpass = (float*)q[8]; P.dw = (float*)q[9]; P.H = (int)q[10];
-        if (!P.Hn || !P.w || !P.alpha || (P.H != 256 && P.H != 32)) return EVAD_ERR_ARG;
-    }
-    return EVAD_OK;
-}
-
-extern "C" int eventad_att_fwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream) {
-    AttGroup g;
-    if (att_group(n_prob, desc, valid, &g)) return EVAD_ERR_ARG;
-    for (int i = 0; i < n_prob; ++i) if (!g.p[i].Sprev || !g.p[i].Snext) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_att_fwd, dim3(n_prob), dim3(256), 0, (hipStream_t)stream, g);
-    return evad_last_error();
-}
-
-extern "C" int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream) {
-    AttGroup g;
-    if (att_group(n_prob, desc, valid, &g)) return EVAD_ERR_ARG;
-    for (int i = 0; i < n_prob; ++i) if (!g.p[i].dSnext || !g.p[i].dHn || !g.p[i].dSpass || !g.p[i].dw) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_att_bwd, dim3(n_prob), dim3(256), 0, (hipStream_t)stream, g);
-    return evad_last_error();
-}
-
+// GRU cell (PyTorch gate order r,z,n): h' = (1-z)*n + z*h,  n = tanh(gi_n + r*gh_n); the gates (r,z,n) are kept for
+// the backward pass; xdrop = h' * mask is the dropout'd input of the next GRU layer (nn.GRU(dropout=0.3),
+// EventAD.py:86).  Backward: dh = dHn (+ dx_extra*mask); dn = dh*(1-z), dz = dh*(h-n), dh_prev = dSpass + dh*z;
+// dgi = (da_r, da_z, da_n), dgh = (da_r, da_z, da_n*r) with da_n = dn*(1-n^2), da_z = dz*z(1-z), da_r = da_n*gh_n*r(1-r).
+// SpatialAttention (EventAD.py:100-138) over the valid tracks of one clip:
+//   s_k = tanh(Hn_k).w ; alpha = softmax_valid(s) ; S'_k = valid ? Hn_k*alpha_k : S_k (state kept).
 // ------------------------------------------------------------------------------------------------
 // Fused recurrent step: GRU cell + SpatialAttention of one clip in ONE workgroup per problem (1024 threads,
 // thread = (track row k = tid>>5, lane c = tid&31) owning hidden columns c, c+32, ...).  The head is a chain
@@ -334,6 +78,8 @@ extern "C" int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int3
 // the row-reduction attention that consumes it (and, on the way back, the attention backward with the cell
 // backward) halves the number of dependent launches; eventad_amd/head_native.py additionally runs GRU layer 1
 // one clip behind layer 0 so both layers share each launch.
+__device__ __forceinline__ float wave_sum(float v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
+
 struct StepProb { const float* gi; const float* gh; const float* hprev; float* gates; float* hn; const float* mask;
                   float* xdrop; const float* w; float* alpha; float* snext; const int* valid; int H; };
 struct StepGroup { StepProb p[3]; int n; };
@@ -600,16 +346,6 @@ extern "C" int eventad_out_bwd(const float* dlog, const float* Wo, const float* 
 
 // column sums (bias gradients): out[n] = sum_r A[r, n]; 64 columns per workgroup, the 4 waves split the
 // rows, fixed-order LDS reduction.
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, int lda, int R, int N, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-    float s = 0.f;
-    if (n < N) for (int r = w; r < R; r += 4) s += A[(size_t)r * lda + n];
-    red[w][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (w == 0 && n < N) out[n] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-}
-
 struct ColGroup { const float* A[8]; float* out[8]; int lda[8], N[8]; int R, n; };
 __global__ __launch_bounds__(256) void k_colsum_g(ColGroup g) {
     __shared__ float red[4][64];
@@ -647,11 +383,6 @@ extern "C" int eventad_colsum_group(int n, const int64_t* desc, int R, void* str
     return evad_last_error();
 }
 
-extern "C" int eventad_colsum(const float* A, int lda, int R, int N, float* out, void* stream) {
-    if (!A || !out || R <= 0 || N <= 0 || lda < N) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_colsum, dim3(evad_blocks(N, 64)), dim3(256), 0, (hipStream_t)stream, A, lda, R, N, out);
-    return evad_last_error();
-}
 
 // ------------------------------------------------------------------------------------------------
 // Optimiser: clip_grad_norm_(max_norm) + AdamW on flat fp32 buffers (utils/train.py:27-53,141-152).

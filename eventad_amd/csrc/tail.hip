@@ -74,25 +74,7 @@ extern "C" int eventad_tail_blend(const float* Z, int ldz, int root_col, const f
     return evad_last_error();
 }
 
-// NCHW -> NHWC for externally supplied ("precomputed") CNN feature maps: out[b,p,c] = in[b,c,p]
-__global__ void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int P, long long total) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    int c = (int)(t % C);
-    long long bp = t / C;
-    int p = (int)(bp % P);
-    long long b = bp / P;
-    out[t] = in[(b * C + c) * (long long)P + p];
-}
-
-extern "C" int eventad_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream) {
-    if (!in || !out || B < 0 || C <= 0 || H <= 0 || W <= 0) return EVAD_ERR_ARG;
-    long long total = (long long)B * C * H * W;
-    if (total == 0) return EVAD_OK;
-    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(evad_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, H * W, total);
-    return evad_last_error();
-}
-
+// NCHW -> NHWC for externally supplied ("precomputed") CNN feature maps: out[b,p,c] = in[b,c,p].
 // All (up to 8) map layout changes of a step in ONE launch, as 32x32 LDS-tiled transposes (coalesced on both sides;
 // the per-element kernel above reads with a stride of H*W floats).  desc: HOST array, 6 int64 per map:
 // [0] in [1] out [2] B [3] C [4] H [5] W.

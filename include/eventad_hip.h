@@ -87,7 +87,6 @@ int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev
 /* ELL -> the reference's edge buffer layout (i64[2,K], event numbering, -1 padded). */
 int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32_t* sid, int N, int max_num_neighbors,
                          int64_t K, int64_t* edges, void* stream);
-int eventad_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, int64_t n, void* stream);
 
 /* ---- (C) first Layer on the event graph: replaces Layer.forward for conv_block1 --------------- */
 /* (conv.py:59-72 = ConvBlock :10-28 + ConvBlockWithSkip :31-56 over MySplineConv.message_lut,
@@ -157,9 +156,8 @@ int eventad_tail_blend(const float* Z, int ldz, int root_col, const float* Zskip
                        const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,
                        const int32_t* n_dev, float div_x, float div_y, const float* bn_scale, const float* bn_shift,
                        const float* skip_scale, const float* skip_shift, float* out, int ldo, void* stream);
-int eventad_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream);
-/* The same for up to 8 maps in one launch (LDS-tiled transposes).  desc = HOST array, 6 int64 per map:
- * [0] in [1] out [2] B [3] C [4] H [5] W. */
+/* NCHW -> NHWC of externally supplied CNN feature maps, up to 8 maps in one launch (LDS-tiled transposes).
+ * desc = HOST array, 6 int64 per map: [0] in [1] out [2] B [3] C [4] H [5] W. */
 int eventad_nchw_to_nhwc_group(int n_maps, const int64_t* desc, void* stream);
 
 /* ---- (F) EventAD head --------------------------------------------------------------------------- */
@@ -179,19 +177,8 @@ int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int lda, const
  * CO f32[B*32,4], target/valid i32[B*32]; labels = bbox[:,4] (nullable). */
 int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, const float* labels, const float* feats,
                         int B, int width, int height, float* X, float* CO, int32_t* target, int32_t* valid, void* stream);
-/* One nn.GRU layer time step, element-wise part (gate order r,z,n) and its backward. */
-int eventad_gru_cell_fwd(const float* gi, const float* gh, const float* hprev, int rows, int H, float* gates,
-                         float* hnew, const float* mask, float* xdrop, void* stream);
-int eventad_gru_cell_bwd(const float* dhn, const float* dx_extra, const float* mask, const float* gates, const float* gh,
-                         const float* hprev, const float* dspass, int rows, int H, float* dgi, float* dgh, float* dsprev,
-                         void* stream);
-/* SpatialAttention over the valid tracks of one clip (EventAD.py:100-138, 320-323) and its backward. */
-/* Up to 3 independent attentions per launch.  desc = HOST array, 12 int64 per problem:
- * [0] Hn [1] Sprev [2] w [3] alpha [4] Snext [5] dSnext [6] dHn_out(0=none) [7] dHn [8] dSpass [9] dw [10] H;
- * valid i32[32] = the clip's track mask (device). */
-int eventad_att_fwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
-int eventad_att_bwd_group(int n_prob, const int64_t* desc, const int32_t* valid, void* stream);
-/* Fused recurrent step of the head (Fuse_GRUNet / SpatialAttention, models/EventAD.py:62-138): GRU cell + attention
+/* Fused recurrent step of the head (Event_GRUNet / Cor_GRUNet cell, gate order r,z,n, + SpatialAttention over the valid
+ * tracks; models/EventAD.py:62-138, 320-323) and its backward: GRU cell + attention
  * of one clip, one 1024-thread workgroup per problem, up to 3 problems per launch.
  * fwd desc = HOST array, 12 int64 per problem: [0] gi [1] gh [2] hprev (= the state the attention keeps for invalid
  * tracks) [3] gates out [4] hn out [5] dropout mask(0=none) [6] xdrop out(0=none) [7] attention w [8] alpha out
@@ -210,17 +197,11 @@ int eventad_gru_att_bwd_group(int n_prob, const int64_t* desc, void* stream);
  * by the last workgroup to reach the tile instead of by a second launch; the value 1 = leave the slabs of a K > 256
  * product un-summed in `part` for a consumer that adds them itself (eventad_gru_att_bwd_group does). */
 int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream);
-/* Up to 3 GRU cells per launch.  desc = HOST array, 12 int64 per cell: fwd [0] gi [1] gh [2] hprev [3] gates
- * [4] hnew [5] mask(0) [6] xdrop(0) [7] H; bwd [0] dhn [1] dx_extra(0) [2] mask(0) [3] gates [4] gh [5] hprev
- * [6] dspass [7] dgi [8] dgh [9] dsprev [10] H.  rows = 32 (one clip). */
-int eventad_gru_cell_fwd_group(int n, const int64_t* desc, void* stream);
-int eventad_gru_cell_bwd_group(int n, const int64_t* desc, void* stream);
 /* fusion[3] Linear(256,2) + summed cross-entropy (EventAD.py:27,280-281) and its backward. */
 int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
                      const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss, void* stream);
 int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
                     float* dWo, float* dbo, void* stream);
-int eventad_colsum(const float* A, int lda, int R, int N, float* out, void* stream);
 /* up to 8 column sums per launch; desc = HOST array, 4 int64 per problem: [0] A [1] out [2] lda [3] N */
 int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream);
 /* clip_grad_norm_ + AdamW on flat buffers (utils/train.py:27-53,141-152).  state f32[8]:

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for must in ("eventad_insert_in_queue", "eventad_insert_in_queue_single", "eventad_fill_edges",   # = ev_graph_cuda
                  "eventad_sort_events", "eventad_build_ell", "eventad_l1_conv1", "eventad_l1_conv2",
                  "eventad_pool_scatter", "eventad_gemm_f32", "eventad_tail_blend", "eventad_roi_pool",
-                 "eventad_gru_cell_fwd", "eventad_att_bwd_group", "eventad_clip_adamw"):
+                 "eventad_gru_att_fwd_group", "eventad_gru_att_bwd_group", "eventad_clip_adamw"):
         assert must in protos
 
 
