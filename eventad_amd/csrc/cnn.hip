@@ -17,6 +17,7 @@ struct ConvP {
     const float* in; const float* w; float* out;
     const float* bias; const float* scale; const float* shift; const float* residual;
     int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, relu;
+    float* part; int ksplit, kchunk;       // split-K: slab z covers k in [z*kchunk, (z+1)*kchunk) and goes to part[z][M][N]
 };
 
 template <int TM, int TN>
@@ -47,12 +48,13 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
         } else { a_base[t] = -1; a_ih[t] = 0; a_iw[t] = 0; }
     }
     float4 ra[AL], rb[BL];
+    const int kend_ = p.ksplit > 1 ? min(K, ((int)blockIdx.z + 1) * p.kchunk) : K;
     auto fetch = [&](int k0) {                                 // slab k0 -> registers (global latency hides under MFMAs)
 #pragma unroll
         for (int t = 0; t < AL; ++t) {
             int f = tid + t * 256, kq = (f & 3) * 4, gk = k0 + kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_base[t] >= 0 && gk < K) {                   // Cin % 4 == 0: the 4 k's share (kh, kw)
+            if (a_base[t] >= 0 && gk < kend_) {               // Cin % 4 == 0: the 4 k's share (kh, kw)
                 int kk = gk / p.Cin, ci = gk % p.Cin, kh = kk / p.KW, kw = kk % p.KW;
                 int ih = a_ih[t] + kh, iw = a_iw[t] + kw;
                 if (ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
         for (int t = 0; t < BL; ++t) {
             int f = tid + t * 256, kr = f / (BN / 4), nq = (f % (BN / 4)) * 4, gk = k0 + kr, gn = n0 + nq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < K && gn < N) v = *(const float4*)(p.w + (size_t)gk * N + gn);      // Cout % 4 == 0
+            if (gk < kend_ && gn < N) v = *(const float4*)(p.w + (size_t)gk * N + gn);  // Cout % 4 == 0
             rb[t] = v;
         }
     };
@@ -80,12 +82,14 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
             *(float4*)&Bs[buf][kr][nq] = rb[t];
         }
     };
-    fetch(0);
+    const int kbeg = p.ksplit > 1 ? (int)blockIdx.z * p.kchunk : 0;
+    const int kend = p.ksplit > 1 ? min(K, kbeg + p.kchunk) : K;
+    fetch(kbeg);
     stage(0);
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < K; k0 += CBK) {
-        const bool more = k0 + CBK < K;
+    for (int k0 = kbeg; k0 < kend; k0 += CBK) {
+        const bool more = k0 + CBK < kend;
         if (more) fetch(k0 + CBK);
 #pragma unroll
         for (int kk = 0; kk < CBK; kk += 2) {
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
             for (int r = 0; r < 16; ++r) {
                 int gm = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (gm >= M) continue;
+                if (p.ksplit > 1) { p.part[((size_t)blockIdx.z * M + gm) * N + gn] = acc[i][j][r]; continue; }
                 float v = acc[i][j][r] + bi;
                 if (p.scale) v = fmaf(v, sc, sh);
                 if (p.residual) v += p.residual[(size_t)gm * N + gn];
@@ -125,21 +130,52 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
         }
 }
 
+// split-K epilogue: slabs summed in slab order (deterministic), then the same epilogue as the one-pass kernel
+__global__ void k_conv_reduce(ConvP p, long long MN) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= MN) return;
+    const int gn = (int)(t % p.Cout);
+    float v = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) v += p.part[(size_t)z * MN + t];
+    if (p.bias) v += p.bias[gn];
+    if (p.scale) v = fmaf(v, p.scale[gn], p.shift[gn]);
+    if (p.residual) v += p.residual[t];
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.out[t] = v;
+}
+
 /* in f32[B,IH,IW,Cin] (NHWC, Cin % 4 == 0), w f32[KH*KW*Cin, Cout] (k = (kh*KW+kw)*Cin+ci, Cout % 4 == 0),
- * out f32[B,OH,OW,Cout]; epilogue: +bias, *scale+shift (folded BatchNorm), +residual (same shape as out), ReLU. */
+ * out f32[B,OH,OW,Cout]; epilogue: +bias, *scale+shift (folded BatchNorm), +residual (same shape as out), ReLU.
+ * workspace (nullable) f32[workspace_floats]: shapes whose output has too few tiles to fill the chip (the 3x3 and
+ * wide 1x1 convolutions of ResNet layers 3-4: 64-128 tiles for 256 CUs) are then computed split-K, slabs summed in
+ * order by a second launch. */
 extern "C" int eventad_conv2d_nhwc(const float* in, const float* w, float* out, const float* bias, const float* scale,
                                    const float* shift, const float* residual, int B, int IH, int IW, int Cin, int OH,
-                                   int OW, int Cout, int KH, int KW, int stride, int pad, int relu, void* stream) {
+                                   int OW, int Cout, int KH, int KW, int stride, int pad, int relu, float* workspace,
+                                   int64_t workspace_floats, void* stream) {
     if (!in || !w || !out || B <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) ||
         (Cout & 3) || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || (scale && !shift) ||
         ((uintptr_t)in & 15) || ((uintptr_t)w & 15))
         return EVAD_ERR_ARG;
-    ConvP p{in, w, out, bias, scale, shift, residual, B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, relu};
-    long long M = (long long)B * OH * OW;
-    if (M * Cout >= 128ll * 128 * 64 && Cout >= 128)
-        hipLaunchKernelGGL((k_conv_f32<2, 2>), dim3((Cout + 127) / 128, (unsigned)((M + 127) / 128)), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((k_conv_f32<1, 1>), dim3((Cout + 63) / 64, (unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    ConvP p{in, w, out, bias, scale, shift, residual, B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, relu, nullptr, 1, 0};
+    const long long M = (long long)B * OH * OW, MN = M * Cout;
+    const int K = KH * KW * Cin;
+    const bool big = M * Cout >= 128ll * 128 * 64 && Cout >= 128;
+    const int bt = big ? 128 : 64;
+    const long long tiles = ((Cout + bt - 1) / bt) * ((M + bt - 1) / bt);
+    if (workspace && tiles < 160 && K >= 512) {
+        int ks = (int)(256 / tiles);
+        if (ks > 8) ks = 8;
+        while (ks > 1 && (K / ks < 128 || (long long)ks * MN > workspace_floats)) --ks;
+        if (ks > 1) {
+            p.ksplit = ks; p.kchunk = ((K + ks - 1) / ks + CBK - 1) / CBK * CBK; p.part = workspace;
+            p.ksplit = (K + p.kchunk - 1) / p.kchunk;
+        }
+    }
+    dim3 grid((Cout + bt - 1) / bt, (unsigned)((M + bt - 1) / bt), p.ksplit);
+    if (big) hipLaunchKernelGGL((k_conv_f32<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else     hipLaunchKernelGGL((k_conv_f32<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (p.ksplit > 1) hipLaunchKernelGGL(k_conv_reduce, dim3(evad_blocks(MN, 256)), dim3(256), 0, (hipStream_t)stream, p, MN);
     return evad_last_error();
 }
 

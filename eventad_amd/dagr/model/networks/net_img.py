@@ -121,8 +121,13 @@ class NativeCNN:
         OH, OW = (IH + 2 * pad - K) // stride + 1, (IW + 2 * pad - K) // stride + 1
         if out is None:
             out = torch.empty((B, OH, OW, Cout), device=self.dev)
+        # split-K scratch for the shapes that cannot fill 256 CUs on their own (layers 3-4): up to 8 slabs of the largest
+        # such output (<= 160 tiles of 128 x 128)
+        if getattr(self, "_ws", None) is None:
+            self._ws = torch.empty(8 * 160 * 128 * 128, device=self.dev)
         call("eventad_conv2d_nhwc", ptr(x), ptr(w), ptr(out), ptr(bias), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
-             ptr(residual), B, IH, IW, Cin, OH, OW, Cout, K, K, stride, pad, relu, torch.cuda.current_stream().cuda_stream)
+             ptr(residual), B, IH, IW, Cin, OH, OW, Cout, K, K, stride, pad, relu, ptr(self._ws), self._ws.numel(),
+             torch.cuda.current_stream().cuda_stream)
         return out, OH, OW
 
     def forward(self, image):

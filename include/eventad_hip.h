@@ -213,10 +213,13 @@ int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_a
 /* ---- (G) CNN feature branch: replaces HookModule.forward over torchvision resnet50 ---------------- */
 /* (reference src/dagr/model/networks/net_img.py:122-134, net.py:41-49).  NHWC fp32 implicit-GEMM convolution
  * on fp32 MFMA: in f32[B,IH,IW,Cin] (Cin % 4 == 0), w f32[KH*KW*Cin, Cout] with k = (kh*KW+kw)*Cin+ci
- * (Cout % 4 == 0), out f32[B,OH,OW,Cout]; epilogue +bias, *scale+shift (folded eval BatchNorm), +residual, ReLU. */
+ * (Cout % 4 == 0), out f32[B,OH,OW,Cout]; epilogue +bias, *scale+shift (folded eval BatchNorm), +residual, ReLU.
+ * workspace f32[workspace_floats] (nullable): lets shapes with too few output tiles for 256 CUs (ResNet layers 3-4)
+ * run split-K -- up to 8 slabs of B*OH*OW*Cout floats, summed in slab order by a second launch. */
 int eventad_conv2d_nhwc(const float* in, const float* w, float* out, const float* bias, const float* scale,
                         const float* shift, const float* residual, int B, int IH, int IW, int Cin, int OH, int OW,
-                        int Cout, int KH, int KW, int stride, int pad, int relu, void* stream);
+                        int Cout, int KH, int KW, int stride, int pad, int relu, float* workspace,
+                        int64_t workspace_floats, void* stream);
 /* stem: bn1 + ReLU + 3x3/2 max-pool (pad 1), NHWC. */
 int eventad_bn_relu_maxpool(const float* in, const float* scale, const float* shift, float* out, int B, int IH, int IW,
                             int C, int OH, int OW, void* stream);

@@ -12,7 +12,10 @@ dev = torch.device("cuda:0")
 raw = synthetic.make_config_batch(cfg)
 data = format_data(raw.to(dev))
 nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
-res = nb.forward(data.pos, data.x, data.batch, B, data.image_feats)
+feats = data.image_feats
+if feats is None:                                            # live-CNN configs: any maps of the right shape will do here
+    feats = [torch.randn(B, c, h, w, device=dev) for c, (h, w) in zip(synthetic.FEATURE_CHANNELS, synthetic.feature_map_sizes(W, H))]
+res = nb.forward(data.pos, data.x, data.batch, B, feats)
 torch.cuda.synchronize()
 ws, g = res["ws"], nb.geom
 N = data.pos.shape[0]

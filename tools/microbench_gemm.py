@@ -2,6 +2,7 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eventad_amd._lib import call, ptr
 st = torch.cuda.current_stream().cuda_stream
+WS = torch.empty(8 * 160 * 128 * 128, device="cuda")          # split-K scratch of eventad_conv2d_nhwc
 def timeit(fn, it=20):
     for _ in range(3): fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -18,5 +19,5 @@ for (B, H, Cin, Cout, Kk, s) in [(8, 64, 64, 64, 3, 1), (8, 64, 256, 64, 1, 1), 
     pad = Kk // 2
     OH = (H + 2 * pad - Kk) // s + 1
     x = torch.randn(B, H, H, Cin, device="cuda"); w = torch.randn(Kk * Kk * Cin, Cout, device="cuda"); o = torch.empty(B, OH, OH, Cout, device="cuda")
-    ms = timeit(lambda: call("eventad_conv2d_nhwc", ptr(x), ptr(w), ptr(o), None, None, None, None, B, H, H, Cin, OH, OH, Cout, Kk, Kk, s, pad, 0, st))
+    ms = timeit(lambda: call("eventad_conv2d_nhwc", ptr(x), ptr(w), ptr(o), None, None, None, None, B, H, H, Cin, OH, OH, Cout, Kk, Kk, s, pad, 0, ptr(WS), WS.numel(), st))
     print("conv B%d %dx%d %d->%d k%d s%d: %.3f ms  %.1f TF" % (B, H, H, Cin, Cout, Kk, s, ms, 2 * B * OH * OH * Cout * Kk * Kk * Cin / ms / 1e9))
