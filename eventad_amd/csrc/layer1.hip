@@ -50,10 +50,10 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
     float* s_root = smem;                                 // [CINP][16]
     float* s_skip = s_root + CINP * 16;                   // [20][16] (SKIP only)
     float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [steps][LS]
-    for (int t = threadIdx.x; t < CINP * 16; t += L1_THREADS) s_root[t] = root[t];
+    if (root) for (int t = threadIdx.x; t < CINP * 16; t += L1_THREADS) s_root[t] = root[t];
     if (SKIP) for (int t = threadIdx.x; t < 20 * 16; t += L1_THREADS) s_skip[t] = wskip[t];
     if (LUT_IN_LDS)
-        for (int t = threadIdx.x; t < steps * CINP * 16; t += L1_THREADS) s_lut[(t / (CINP * 16)) * LS + t % (CINP * 16)] = lut[t];
+        for (int t = threadIdx.x; t < (steps + (root ? 0 : 1)) * CINP * 16; t += L1_THREADS) s_lut[(t / (CINP * 16)) * LS + t % (CINP * 16)] = lut[t];
     __syncthreads();
 
     const int l4 = (threadIdx.x & 3) * 4;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
             int4 svn = sv; uint2 cvn = cv;
             if (q < 3 && e0 + 4 < d) { svn = sp[q + 1]; cvn = cp[q + 1]; }
             if (e0 + 1 < d) load_row<CINP>(xin + (size_t)sv.y * CINP, xb);
-            edge(xa, cv.x & 0xffff);
+            edge(xa, (q == 0 && !root) ? steps : (int)(cv.x & 0xffff));   // folded root: the self edge reads row `steps`
             if (e0 + 1 < d) {
                 if (e0 + 2 < d) load_row<CINP>(xin + (size_t)sv.z * CINP, xa);
                 edge(xb, cv.x >> 16);
@@ -97,10 +97,12 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
             sv = svn; cv = cvn;
         }
     }
-    float x[CINP];
-    load_row<CINP>(xin + (size_t)node * CINP, x);
-    float4 m = matvec4<CINP>(x, s_root + l4);                                 // root weight (spline_conv.py:72-73)
-    acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    if (root) {                                              // root weight (spline_conv.py:72-73); NULL = the caller appended
+        float x[CINP];                                       // lut[steps] = lut[0] + root, the matrix of the self edge
+        load_row<CINP>(xin + (size_t)node * CINP, x);
+        float4 m = matvec4<CINP>(x, s_root + l4);
+        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+    }
     float4 sc = *(const float4*)(scale + l4), sh = *(const float4*)(shift + l4);
     float4 y = make_float4(fmaf(acc.x, sc.x, sh.x), fmaf(acc.y, sc.y, sh.y), fmaf(acc.z, sc.z, sh.z), fmaf(acc.w, sc.w, sh.w));
     if (SKIP) {
@@ -120,7 +122,7 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
                      const float* sscale, const float* sshift, float* out, int N, int steps, int max_nb, hipStream_t st) {
     constexpr int LS = CINP * 16 + 16;
     size_t fixed = sizeof(float) * (CINP * 16 + (SKIP ? 320 : 0));
-    size_t with_lut = fixed + sizeof(float) * (size_t)steps * LS;
+    size_t with_lut = fixed + sizeof(float) * (size_t)(steps + (root ? 0 : 1)) * LS;
     if (max_nb != 16) return EVAD_ERR_ARG;              // the ELL row is read as 4 x int4 + 2 x uint4
     dim3 grid(evad_blocks(N, L1_THREADS / 4)), block(L1_THREADS);
     if (with_lut <= 80 * 1024) {            // two workgroups per CU (160 KiB LDS)
@@ -145,7 +147,7 @@ extern "C" int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const 
                                 const float* lut /* [steps][20][16] */, const float* root /* [20][16] */,
                                 const float* bn_scale, const float* bn_shift, float* y1, int N, int steps,
                                 int max_num_neighbors, void* stream) {
-    if (!x0s || !ell_src || !ell_step || !deg || !lut || !root || !bn_scale || !bn_shift || !y1 || N < 0 || steps < 1)
+    if (!x0s || !ell_src || !ell_step || !deg || !lut || !bn_scale || !bn_shift || !y1 || N < 0 || steps < 1)
         return EVAD_ERR_ARG;
     if (N == 0) return EVAD_OK;
     return launch_l1<20, false>(x0s, ell_src, ell_step, deg, lut, root, bn_scale, bn_shift, nullptr, nullptr, nullptr,
@@ -158,7 +160,7 @@ extern "C" int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t
                                 const float* bn_scale, const float* bn_shift, const float* wskip /* [20][16] */,
                                 const float* skip_scale, const float* skip_shift, float* y2, int N, int steps,
                                 int max_num_neighbors, void* stream) {
-    if (!y1 || !x0s || !ell_src || !ell_step || !deg || !lut || !root || !bn_scale || !bn_shift || !wskip ||
+    if (!y1 || !x0s || !ell_src || !ell_step || !deg || !lut || !bn_scale || !bn_shift || !wskip ||
         !skip_scale || !skip_shift || !y2 || N < 0 || steps < 1)
         return EVAD_ERR_ARG;
     if (N == 0) return EVAD_OK;

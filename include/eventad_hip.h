@@ -91,7 +91,8 @@ int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32
 /* ---- (C) first Layer on the event graph: replaces Layer.forward for conv_block1 --------------- */
 /* (conv.py:59-72 = ConvBlock :10-28 + ConvBlockWithSkip :31-56 over MySplineConv.message_lut,
  * spline_conv.py:39-78).  lut = MySplineConv.lut_weights re-ordered by spiral step, [steps][Cin_pad][16];
- * root = conv.lin.weight^T [Cin_pad][16]; bn_* = folded eval BatchNorm (components.py:9-12). */
+ * root = conv.lin.weight^T [Cin_pad][16], or NULL when the caller appended lut[steps] = lut[0] + root (the matrix of the
+ * self edge that opens every ELL row: one mat-vec less per node); bn_* = folded eval BatchNorm (components.py:9-12). */
 int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
                      const float* lut, const float* root, const float* bn_scale, const float* bn_shift, float* y1,
                      int N, int steps, int max_num_neighbors, void* stream);
