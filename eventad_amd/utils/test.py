@@ -1,123 +1,120 @@
-"""collect_predictions of the reference's test loop (utils/test.py:9-179) without per-object host syncs.
+"""collect_predictions of the EventAD test loop (interface of the reference's utils/test.py:9-179) without per-object
+host syncs.
 
-The reference pulls every score and label off the device with `.item()` (two syncs per object, plus one per
-box for the first-anomaly scan).  Here a model that offers `predict_tensors(data, labels)` -- the MI355X
-`EventADModel` does -- hands back the padded [B, 31] logit/target/valid tables of the batch and ONE transfer
-per batch brings them to the host; any other model is driven through its `(losses, outputs, labels)` return
-exactly as the reference does.  The returned dictionary has the reference's keys, value types and ordering,
-including its indexing habits (the j-th NON-EMPTY clip of a batch is looked up as `sample_id[j]` /
-`sequence[j]`; box i is paired with `sequence[i]` in the first-anomaly scan)."""
+The reference reads every score and label off the device with `.item()` (two syncs per object, one more per box for the
+first-anomaly scan).  Here a model that offers `predict_tensors(data, labels)` -- the MI355X `EventADModel` does --
+returns the padded [B, 31] logit / target / valid tables of the batch and ONE transfer per batch brings them to the
+host; any other model is driven through its `(losses, outputs, labels)` return.  The result dictionary has the
+reference's keys, value types and ordering, including its indexing habits: the j-th NON-EMPTY clip of a batch is
+looked up as `sample_id[j]` / `sequence[j]`, and box i is paired with `sequence[i]` when the first anomalous frame of
+a video is searched.  Pinned by tests/golden/eval_golden.json (made by running the reference's function)."""
+import traceback
+
 import numpy as np
 import torch
 
 from .utils import parse_sample_id
 
-try:                                                           # progress bar as in the reference when tqdm is around
+try:
     from tqdm import tqdm
 except Exception:                                              # pragma: no cover
     def tqdm(it, **kw):
         return it
 
 
-def _batch_tables(model, data, labels):
-    """-> per non-empty clip (in clip order): (scores list[float], labels list[int])."""
+def _tables_of(model, data, labels):
+    """[(scores, labels)] per non-empty clip, clip order; score = logit of class 1 as a Python float (None = unusable)."""
     if hasattr(model, "predict_tensors"):
         logits, valid, targets = model.predict_tensors(data, labels)
-        packed = torch.cat([logits[..., 1].float(), valid.float(), targets.float()], dim=1).cpu().numpy()   # one D2H copy
+        host = torch.cat([logits[..., 1].float(), valid.float(), targets.float()], dim=1).cpu().numpy()    # the one copy
         T = logits.shape[1]
-        sc, va, tg = packed[:, :T], packed[:, T:2 * T] > 0.5, packed[:, 2 * T:]
-        out = []
-        for b in range(sc.shape[0]):
-            ks = np.nonzero(va[b])[0]
-            if ks.size:
-                out.append(([float(np.float32(sc[b, k])) for k in ks], [int(tg[b, k]) for k in ks]))
-        return out
-    losses, batch_outputs, batch_labels = model(data, labels, testing=True)
-    out = []
-    for frame_outputs, frame_labels in zip(batch_outputs, batch_labels):
+        score, keep, target = host[:, :T], host[:, T:2 * T] > 0.5, host[:, 2 * T:]
+        return [([float(np.float32(score[b, k])) for k in ks], [int(target[b, k]) for k in ks])
+                for b in range(score.shape[0]) for ks in [np.flatnonzero(keep[b])] if ks.size]
+    _, outputs, targets = model(data, labels, testing=True)
+    tables = []
+    for outs, tgts in zip(outputs, targets):
         scores = []
-        for o in frame_outputs:
-            if o.dim() == 1:
-                scores.append(o[1].item())
-            elif o.dim() == 2:
-                scores.append(o[0, 1].item())
+        for o in outs:
+            if o.dim() in (1, 2):
+                scores.append((o[1] if o.dim() == 1 else o[0, 1]).item())
             else:
-                print(f"Warning: Unexpected output dimensions: {o.dim()}, shape: {o.shape}")
+                print("[collect] output of rank %d ignored (shape %s)" % (o.dim(), tuple(o.shape)))
                 scores.append(None)
-        out.append((scores, [l.item() for l in frame_labels]))
-    return out
+        tables.append((scores, [t.item() for t in tgts]))
+    return tables
+
+
+class _Collector:
+    def __init__(self):
+        self.scores, self.labels, self.ids = [], [], []
+        self.frame_data, self.first_anomaly, self.video_predictions = {}, {}, {}
+
+    def note_anomalies(self, anomalous, video_ids, batch_ids):
+        """utils/test.py:74-83: box i <-> video_ids[i], frame id parsed from batch_ids[i]."""
+        if not isinstance(batch_ids, list):
+            return
+        for i, (flag, video) in enumerate(zip(anomalous, video_ids)):
+            if flag and i < len(batch_ids):
+                frame = parse_sample_id(batch_ids[i])[1]
+                if video not in self.first_anomaly or frame < self.first_anomaly[video]:
+                    self.first_anomaly[video] = frame
+
+    def add(self, sample_id, video, score, label):
+        frame = parse_sample_id(sample_id)[1]
+        self.scores.append(score); self.labels.append(label); self.ids.append(sample_id)
+        cell = self.frame_data.setdefault(video, {}).setdefault(frame, {'scores': [], 'labels': []})
+        cell['scores'].append(score); cell['labels'].append(label)
+        per_video = self.video_predictions.setdefault(video, {})
+        per_video[frame] = max(per_video.get(frame, 0.0), score)
 
 
 def collect_predictions(model, test_loader, device, video_toa=None, threshold=0.5):
     """Same arguments and result dictionary as the reference's collect_predictions."""
     from dagr.utils.buffers import format_data                 # the mirror registered by eventad_amd.compat.install()
-    print("Starting to collect prediction results...")
-    all_labels, all_scores, sample_ids = [], [], []
-    frame_data, video_first_anomaly, video_predictions = {}, {}, {}
-    valid_batch_count = skipped_batch_count = 0
+    print("[collect] running the test set ...")
+    acc = _Collector()
+    done = skipped = 0
     with torch.no_grad():
         for i, data in enumerate(tqdm(test_loader, desc="Testing Progress")):
             try:
-                data = data.to(device)
-                data = format_data(data)
-                batch_ids = data.sample_id if hasattr(data, 'sample_id') else [f"batch_{i}_sample_{j}" for j in range(len(data.x))]
-                if not hasattr(data, 'bbox') or data.bbox is None or (isinstance(data.bbox, torch.Tensor) and data.bbox.shape[0] == 0):
-                    print(f"Test batch {i} has no valid bounding boxes, skipping")
-                    skipped_batch_count += 1
+                data = format_data(data.to(device))
+                boxes = getattr(data, 'bbox', None)
+                if boxes is None or (isinstance(boxes, torch.Tensor) and boxes.shape[0] == 0):
+                    print("[collect] batch %d has no boxes, skipped" % i)
+                    skipped += 1
                     continue
-                labels = data.bbox[:, 4]
-                if hasattr(data, 'sequence'):
-                    video_ids = data.sequence
-                    if isinstance(video_ids, str):
-                        video_ids = [video_ids] * len(labels)
-                else:
-                    video_ids = [f"batch_{i}"] * len(labels)
-                # first anomalous frame per video (utils/test.py:74-83): box i is paired with video_ids[i]
-                anomalous = (labels > 0.5).cpu().numpy()                                       # one transfer for all boxes
-                for label_idx, (is_anom, vid_id) in enumerate(zip(anomalous, video_ids)):
-                    if is_anom and isinstance(batch_ids, list) and label_idx < len(batch_ids):
-                        _, frame_id, _ = parse_sample_id(batch_ids[label_idx])
-                        if vid_id not in video_first_anomaly or frame_id < video_first_anomaly[vid_id]:
-                            video_first_anomaly[vid_id] = frame_id
-                tables = _batch_tables(model, data, labels)
-                valid_batch_count += 1
-                for j, (scores, labs) in enumerate(tables):
-                    vid_id = video_ids[j] if j < len(video_ids) else f"batch_{i}"
-                    for k, (score, label) in enumerate(zip(scores, labs)):
-                        if score is None:
-                            continue
-                        if isinstance(batch_ids, list) and j < len(batch_ids):
-                            sample_id = f"{batch_ids[j]}_{k}"
-                        else:
-                            sample_id = f"batch_{i}_frame_{j}_obj_{k}"
-                        _, frame_id, obj_id = parse_sample_id(sample_id)
-                        all_scores.append(score)
-                        all_labels.append(label)
-                        sample_ids.append(sample_id)
-                        fd = frame_data.setdefault(vid_id, {}).setdefault(frame_id, {'scores': [], 'labels': []})
-                        fd['scores'].append(score)
-                        fd['labels'].append(label)
-                        vp = video_predictions.setdefault(vid_id, {})
-                        vp[frame_id] = max(vp.get(frame_id, 0.0), score)
-            except Exception as e:
-                print(f"Error processing batch {i}: {e}")
-                import traceback
+                batch_ids = data.sample_id if hasattr(data, 'sample_id') else ["batch_%d_sample_%d" % (i, j) for j in range(len(data.x))]
+                labels = boxes[:, 4]
+                video_ids = getattr(data, 'sequence', None)
+                if video_ids is None:
+                    video_ids = ["batch_%d" % i] * len(labels)
+                elif isinstance(video_ids, str):
+                    video_ids = [video_ids] * len(labels)
+                acc.note_anomalies((labels > 0.5).cpu().numpy(), video_ids, batch_ids)            # one transfer for all boxes
+                tables = _tables_of(model, data, labels)
+                done += 1
+                for j, (scores, targets) in enumerate(tables):
+                    video = video_ids[j] if j < len(video_ids) else "batch_%d" % i
+                    named = isinstance(batch_ids, list) and j < len(batch_ids)
+                    for k, (score, target) in enumerate(zip(scores, targets)):
+                        if score is not None:
+                            acc.add("%s_%d" % (batch_ids[j], k) if named else "batch_%d_frame_%d_obj_%d" % (i, j, k), video, score, target)
+            except Exception as e:                             # the reference logs and moves on (utils/test.py:147-152)
+                print("[collect] batch %d failed: %s" % (i, e))
                 traceback.print_exc()
-                skipped_batch_count += 1
-                continue
-    if not all_labels:
+                skipped += 1
+    if not acc.labels:
         raise RuntimeError("No valid predictions or labels collected, please check dataset and model")
-    print(f"Testing complete: Valid batches {valid_batch_count}/{len(test_loader)}, Skipped batches {skipped_batch_count}")
-    print(f"Collected predictions for {len(all_labels)} samples")
-    all_preds = np.array([1 if score > threshold else 0 for score in all_scores])
+    print("[collect] %d of %d batches used, %d skipped, %d objects" % (done, len(test_loader), skipped, len(acc.labels)))
     return {
-        'all_preds': all_preds,
-        'all_labels': np.array(all_labels),
-        'all_scores': np.array(all_scores),
-        'sample_ids': sample_ids,
-        'frame_data': frame_data,
-        'video_first_anomaly': video_first_anomaly,
-        'video_predictions': video_predictions,
-        'valid_batch_count': valid_batch_count,
-        'skipped_batch_count': skipped_batch_count,
+        'all_preds': np.array([1 if s > threshold else 0 for s in acc.scores]),
+        'all_labels': np.array(acc.labels),
+        'all_scores': np.array(acc.scores),
+        'sample_ids': acc.ids,
+        'frame_data': acc.frame_data,
+        'video_first_anomaly': acc.first_anomaly,
+        'video_predictions': acc.video_predictions,
+        'valid_batch_count': done,
+        'skipped_batch_count': skipped,
     }
