@@ -36,20 +36,47 @@ __global__ __launch_bounds__(256) void k_tail_blend(const float* __restrict__ Z,
     if (node >= n) return;
     float acc = 0.f;
     const unsigned e0 = rowptr[node], e1 = rowptr[node + 1];
-    for (unsigned e = e0; e < e1; ++e) {
-        int s = csr_src[e], pk = csr_dxy[e];
-        int dx = (int)(short)(pk & 0xffff), dy = pk >> 16;
-        // LUT grid attribute (spline_conv.py:27-30): d / (2*M*size) + 0.5
-        float ax = __fadd_rn(__fdiv_rn((float)dx, div_x), 0.5f), ay = __fadd_rn(__fdiv_rn((float)dy, div_y), 0.5f);
-        int ix0, ix1, iy0, iy1; float bx0, bx1, by0, by1;
-        basis1(ax, &ix0, &ix1, &bx0, &bx1);
-        basis1(ay, &iy0, &iy1, &by0, &by1);
-        const float* zr = Z + (size_t)s * ldz + c;
-        float m = __fmul_rn(__fmul_rn(bx0, by0), zr[(ix0 + 5 * iy0) * 64]);
-        m = fmaf(__fmul_rn(bx1, by0), zr[(ix1 + 5 * iy0) * 64], m);
-        m = fmaf(__fmul_rn(bx0, by1), zr[(ix0 + 5 * iy1) * 64], m);
-        m = fmaf(__fmul_rn(bx1, by1), zr[(ix1 + 5 * iy1) * 64], m);
-        acc += m;
+    // Up to 64 edges at a time: lane l fetches edge l's source and offset (ONE coalesced load each instead of a
+    // dependent pair per edge) and works out that edge's 4 taps; the taps are then broadcast edge by edge, so the
+    // Z gathers of consecutive edges are independent loads in flight together.  Messages are still added in
+    // ascending edge order (= the reference's order inside a destination).
+    for (unsigned eb = e0; eb < e1; eb += 64) {
+        const int ne = min(64u, e1 - eb);
+        int s = 0, o00 = 0, o10 = 0, o01 = 0, o11 = 0;
+        float w00 = 0.f, w10 = 0.f, w01 = 0.f, w11 = 0.f;
+        if (c < ne) {
+            s = csr_src[eb + c];
+            const int pk = csr_dxy[eb + c];
+            const int dx = (int)(short)(pk & 0xffff), dy = pk >> 16;
+            // LUT grid attribute (spline_conv.py:27-30): d / (2*M*size) + 0.5
+            const float ax = __fadd_rn(__fdiv_rn((float)dx, div_x), 0.5f), ay = __fadd_rn(__fdiv_rn((float)dy, div_y), 0.5f);
+            int ix0, ix1, iy0, iy1; float bx0, bx1, by0, by1;
+            basis1(ax, &ix0, &ix1, &bx0, &bx1);
+            basis1(ay, &iy0, &iy1, &by0, &by1);
+            o00 = (ix0 + 5 * iy0) * 64; o10 = (ix1 + 5 * iy0) * 64; o01 = (ix0 + 5 * iy1) * 64; o11 = (ix1 + 5 * iy1) * 64;
+            w00 = __fmul_rn(bx0, by0); w10 = __fmul_rn(bx1, by0); w01 = __fmul_rn(bx0, by1); w11 = __fmul_rn(bx1, by1);
+        }
+        for (int j0 = 0; j0 < ne; j0 += 4) {                 // 4 edges = 16 independent gathers per trip
+            float z[4][4], ww[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + u, ne - 1);
+                const float* zr = Z + (size_t)__shfl(s, j, 64) * ldz + c;
+                z[u][0] = zr[__shfl(o00, j, 64)]; z[u][1] = zr[__shfl(o10, j, 64)];
+                z[u][2] = zr[__shfl(o01, j, 64)]; z[u][3] = zr[__shfl(o11, j, 64)];
+                ww[u][0] = __shfl(w00, j, 64); ww[u][1] = __shfl(w10, j, 64); ww[u][2] = __shfl(w01, j, 64); ww[u][3] = __shfl(w11, j, 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u < ne) {
+                    float m = __fmul_rn(ww[u][0], z[u][0]);
+                    m = fmaf(ww[u][1], z[u][1], m);
+                    m = fmaf(ww[u][2], z[u][2], m);
+                    m = fmaf(ww[u][3], z[u][3], m);
+                    acc += m;
+                }
+            }
+        }
     }
     acc += Z[(size_t)node * ldz + root_col * 64 + c];
     float y = fmaf(acc, scale[c], shift[c]);
