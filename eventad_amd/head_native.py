@@ -170,16 +170,16 @@ class NativeHead:
             self.D1, self.D2 = w["D"][:R], w["D"][R:]
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
-        # input projections of every clip at once
-        self._gg((0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, P[ev + "bias_ih_l0"]),
-                 (0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, P[co + "bias_ih_l0"]))
+        # input projections of every clip at once: they ride in the first stage's launch (independent problems)
+        input_proj = [(0, 1, w["X"], 64, P[ev + "weight_ih_l0"], 64, w["GI0"], 768, R, 768, 64, P[ev + "bias_ih_l0"]),
+                      (0, 1, w["CO"], 4, P[co + "weight_ih_l0"], 4, w["GIC"], 96, R, 96, 4, P[co + "bias_ih_l0"])]
         # rows [0, NT) of S0/S1/SC are the initial hidden state: zero at allocation and never written
         # The clip-to-clip hidden-state chain (EventAD.py:211-323) as a wavefront: stage b runs GRU layer 0 and the
         # coordinate GRU on clip b and GRU layer 1 on clip b-1 (its input, the dropout'd layer-0 output of clip
         # b-1, and its state, the layer-1 attention of clip b-2, are both a stage old), so one stage is two
         # dependent launches -- a grouped GEMM and a fused cell+attention -- instead of five.
         for b in range(B + 1):
-            gemms, steps = [], []
+            gemms, steps = (list(input_proj) if b == 0 else []), []
             if b < B:
                 r0, r1 = b * NT, (b + 1) * NT
                 gemms += [(0, 1, w["S0"][r0:r1], 256, P[ev + "weight_hh_l0"], 256, w["GH0"][r0:r1], 768, NT, 768, 256, P[ev + "bias_hh_l0"]),
