@@ -33,7 +33,8 @@ def _level(L):
     return n, L.x[:n].cpu(), L.npos[:n].cpu(), L.nbatch[:n].cpu().long(), torch.stack([src, dst])
 
 
-CASES = [(64, 64, 3000, 2, 50000), (256, 256, 20000, 3, 50000), (256, 256, 6000, 2, 400000)]
+# the third case is dense (72 events per 3x3 search window: the spiral-walk edge search), the others sparse (row scan)
+CASES = [(64, 64, 3000, 2, 50000), (256, 256, 20000, 3, 50000), (64, 64, 33000, 2, 50000), (256, 256, 6000, 2, 400000)]
 
 
 @pytest.mark.parametrize("W,H,n,B,span", CASES)
@@ -123,3 +124,28 @@ def test_gemm_matches_torch():
              torch.cuda.current_stream().cuda_stream)
         ref = (A.double() @ Bm.double()).float()
         assert torch.allclose(C, ref, atol=1e-4, rtol=1e-4)
+
+
+def test_both_edge_search_kernels_give_the_same_rows():
+    """Row scan (sparse windows) and register-row spiral walk (dense windows) on the same batch: identical ELL rows,
+    degrees, pooled graph -- whichever the occupancy heuristic would pick."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    W = H = 256
+    data = synthetic.make_batch(W, H, 30000, 3, with_image=False, precomputed_feats=True)
+    data = dagr_ref.format_data(data)
+    dev = torch.device("cuda:0")
+    outs = []
+    for variant in (0, 1):
+        nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
+        nb.ell_variant = variant
+        res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), 3, [m.to(dev) for m in data.image_feats])
+        torch.cuda.synchronize()
+        ws = res["ws"]
+        live = torch.arange(16, device=dev).view(1, -1) < ws["deg"].view(-1, 1)
+        L = ws["levels"][0]
+        n, e = int(L.n_dev.item()), int(L.e_dev.item())
+        outs.append((ws["deg"].clone(), torch.where(live, ws["ell_src"], -1), torch.where(live, ws["ell_step"].int(), -1),
+                     L.csr_src[:e].clone(), L.rowptr[: n + 1].clone(), res["out4"]["x"][: int(res["out4"]["n_dev"].item())].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
