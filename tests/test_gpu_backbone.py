@@ -34,7 +34,9 @@ def _level(L):
 
 
 # the third case is dense (72 events per 3x3 search window: the spiral-walk edge search), the others sparse (row scan)
-CASES = [(64, 64, 3000, 2, 50000), (256, 256, 20000, 3, 50000), (64, 64, 33000, 2, 50000), (256, 256, 6000, 2, 400000)]
+# ... and 12 clips make the level-0 slot table (56*40*13 = 29120 slots) longer than one pass of the single-workgroup scans
+CASES = [(64, 64, 3000, 2, 50000), (256, 256, 20000, 3, 50000), (64, 64, 33000, 2, 50000), (256, 256, 6000, 2, 400000),
+         (64, 64, 1500, 12, 50000)]
 
 
 @pytest.mark.parametrize("W,H,n,B,span", CASES)
