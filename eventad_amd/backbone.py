@@ -309,9 +309,7 @@ class NativeBackbone:
                 self._c("eventad_pool_scatter", _rp(Lp.y), 64, 64, _rp(fmap), fmap.shape[1], fmap.shape[2], 64,
                      _rp(Lp.npos), _rp(Lp.npix), _rp(Lp.nbatch), None, None, Lp.n_max, _rp(Lp.n_dev), g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
-                     ptr(Lp.node_slot_in), ptr(ws["flags_tail"]), 1, st)
-                self._c("eventad_pool_edges_mark_csr", _rp(Lp.rowptr), _rp(Lp.csr_src), ptr(Lp.node_slot_in), Lp.n_max,
-                     _rp(Lp.n_dev), L.nx, L.ny, B, ptr(L.bitmap), ptr(ws["flags_tail"]), 1, st)
+                     ptr(Lp.node_slot_in), ptr(ws["flags_tail"]), 1, _rp(Lp.rowptr), _rp(Lp.csr_src), ptr(L.bitmap), st)   # + edge marks
                 if L.S <= 131072:
                     self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
                          _rp(Lp.nbatch), ptr(L.bitmap), L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),

@@ -29,6 +29,14 @@ __device__ __forceinline__ void bilin_setup(float px_norm, float py_norm, float 
     *x0 = (int)fx0; *y0 = (int)fy0; *fx = ix - fx0; *fy = iy - fy0;
 }
 
+// grid_cluster (torch_cluster): c_d = (int64)((pos_d - 0) / size_d); slot = cx + nx*cy + nx*ny*(clip + t-cell), clamped into the table
+__device__ __forceinline__ int pool_slot_of(float px, float py, float pt, int b, float vsx, float vsy, int nx, int ny, int S, bool* bad) {
+    int cx = (int)__fdiv_rn(px, vsx), cy = (int)__fdiv_rn(py, vsy), ct = (int)pt;
+    long long sl = (long long)cx + (long long)nx * cy + (long long)nx * ny * (b + ct);
+    *bad = sl < 0 || sl >= S;
+    return (int)(sl < 0 ? 0 : (sl >= S ? S - 1 : sl));
+}
+
 // 16 lanes per node, 16 nodes per 256-thread block.
 template <bool MEAN>
 __global__ __launch_bounds__(256) void k_pool_scatter(
@@ -37,7 +45,8 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
     const int* __restrict__ key_s, const int* __restrict__ nidx, int n_max, const int* __restrict__ n_dev,
     int W, int H, float vsx, float vsy, int nx, int ny, int S,
     unsigned* __restrict__ feat, unsigned long long* __restrict__ sums, double* __restrict__ tsum,
-    unsigned* __restrict__ cnt, int* __restrict__ maxidx, int* __restrict__ node_slot, unsigned* __restrict__ flags) {
+    unsigned* __restrict__ cnt, int* __restrict__ maxidx, int* __restrict__ node_slot, unsigned* __restrict__ flags,
+    const unsigned* __restrict__ rowptr, const int* __restrict__ csr_src, unsigned* __restrict__ bitmap) {
     const int n = n_dev ? min(*n_dev, n_max) : n_max;
     const int node = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int lane = threadIdx.x & 15;
@@ -46,11 +55,9 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
     int b, ipx, ipy;
     if (key_s) { int k = key_s[node]; ipx = k % W; ipy = (k / W) % H; b = k / (W * H); }
     else       { ipx = npix[2 * node]; ipy = npix[2 * node + 1]; b = nbatch[node]; }
-    // grid_cluster (torch_cluster): c_d = (int64)((pos_d - 0) / size_d)
-    int cx = (int)__fdiv_rn(px, vsx), cy = (int)__fdiv_rn(py, vsy), ct = (int)pt;
-    long long slot_ll = (long long)cx + (long long)nx * cy + (long long)nx * ny * (b + ct);
-    if (slot_ll < 0 || slot_ll >= S) { if (lane == 0) atomicOr(flags, EVAD_FLAG_POOL_WINDOW); slot_ll = slot_ll < 0 ? 0 : S - 1; }
-    const int slot = (int)slot_ll;
+    bool bad;
+    const int slot = pool_slot_of(px, py, pt, b, vsx, vsy, nx, ny, S, &bad);
+    if (bad && lane == 0) atomicOr(flags, EVAD_FLAG_POOL_WINDOW);
     const int C = Ca + Cm;
     unsigned* frow = feat + (size_t)slot * C;
     for (int c = lane; c < Ca; c += 16) {
@@ -85,6 +92,16 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
         atomicAdd(&cnt[slot], 1u);
         atomicMax(&maxidx[slot], (nidx ? nidx[node] : node) + 1);       // stored +1: a zero-filled table means 'none'
         node_slot[node] = slot;
+    }
+    // pooled-edge marks of this node's incoming edges (pooling.py:59-64), fused here: the slot of a source is a pure
+    // function of its position, so it is recomputed instead of waiting for that node's own node_slot write
+    if (bitmap) {
+        for (unsigned e = rowptr[node] + lane; e < rowptr[node + 1]; e += 16) {
+            const int src = csr_src[e];
+            bool sbad;
+            const int ss = pool_slot_of(npos[3 * src], npos[3 * src + 1], npos[3 * src + 2], nbatch[src], vsx, vsy, nx, ny, S, &sbad);
+            evad_mark_edge(ss, slot, nx, ny, bitmap, flags);
+        }
     }
 }
 
@@ -136,9 +153,11 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
                                     const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx,
                                     float vsy, int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums,
                                     double* tsum, uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags,
-                                    int prezeroed, void* stream) {
+                                    int prezeroed, const uint32_t* rowptr, const int32_t* csr_src, uint32_t* bitmap,
+                                    void* stream) {
     if (!xa || !npos || !feat || !sums || !tsum || !cnt || !maxidx || !node_slot || !flags || (!key_s && (!npix || !nbatch)) ||
-        (Cm > 0 && !map_nhwc) || Ca < 0 || Cm < 0 || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0 || vsx <= 0 || vsy <= 0)
+        (Cm > 0 && !map_nhwc) || Ca < 0 || Cm < 0 || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0 || vsx <= 0 || vsy <= 0 ||
+        (bitmap && (!rowptr || !csr_src || key_s || !nbatch)))
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int S = nx * ny * (B + 1), C = Ca + Cm;
@@ -161,14 +180,14 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
         if (!n_dev || key_s || C > 128) return EVAD_ERR_ARG;                     // pooled levels only
         hipLaunchKernelGGL(k_pool_scatter<false>, grid, block, 0, st, xa, lda, 0, map_nhwc, map_h, map_w, 0, npos, npix,
                            nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
-                           tsum, cnt, maxidx, node_slot, flags);
+                           tsum, cnt, maxidx, node_slot, flags, rowptr, csr_src, bitmap);
         hipLaunchKernelGGL(k_pool_mean_gather, dim3(evad_blocks(S, 4)), dim3(256), 0, st, xa, lda, Ca, map_nhwc, map_h, map_w,
                            Cm, npos, nbatch, node_slot, n_max, n_dev, W, H, S, (float*)feat);
     }
     else
         hipLaunchKernelGGL(k_pool_scatter<false>, grid, block, 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, npix,
                            nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
-                           tsum, cnt, maxidx, node_slot, flags);
+                           tsum, cnt, maxidx, node_slot, flags, rowptr, csr_src, bitmap);
     return evad_last_error();
 }
 

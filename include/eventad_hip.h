@@ -105,12 +105,15 @@ int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t* ell_src, 
 /* Slot table over S = nx*ny*(B+1) voxel slots: feat u32[S,Ca+Cm], sums u64[S,2], tsum 8 bytes[S] (2^-40 fixed point),
  * cnt u32[S], maxidx i32[S].  Level 0 passes key_s (pixel keys) and nidx = sid; pooled levels pass
  * npix/nbatch and n_dev (device-side node count).  The tables are cleared first unless prezeroed != 0 (the caller
- * cleared them, e.g. with one memset over the tables of every level). */
+ * cleared them, e.g. with one memset over the tables of every level).  bitmap (nullable, pooled levels only, already
+ * cleared): also mark, for every incoming CSR edge (rowptr/csr_src) of every node, the source voxel in the destination
+ * voxel's neighbour bitmap (= eventad_pool_edges_mark_csr in the same launch). */
 int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
                          const float* npos, const int32_t* npix, const int32_t* nbatch, const int32_t* key_s,
                          const int32_t* nidx, int n_max, const int32_t* n_dev, int W, int H, float vsx, float vsy,
                          int nx, int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums, double* tsum,
-                         uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, int prezeroed, void* stream);
+                         uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, int prezeroed,
+                         const uint32_t* rowptr, const int32_t* csr_src, uint32_t* bitmap, void* stream);
 /* Level-0 pooling without atomics: one wave per voxel slot walks the slot's pixel rows in the pixel CSR
  * (events of a voxel row are contiguous in sorted order), samples the 64-channel CNN map per member and
  * keeps running maxima in registers.  vx_lo i32[nx+1] / vy_lo i32[ny+1] = first pixel of each voxel column
