@@ -229,7 +229,7 @@ int evad_gemm(bool ta, bool tb, const float* A, int lda, const float* Bm, int ld
         dim3 grid((N + 63) / 64);
         if (tb) hipLaunchKernelGGL(k_gemm_m32<true>, grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, N, K, epi);
         else    hipLaunchKernelGGL(k_gemm_m32<false>, grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, N, K, epi);
-    } else if ((long long)M * N >= 128ll * 128 * 256) {
+    } else if ((long long)M * N >= 128ll * 128 * 256 && K >= 256) {   // shallow K (the tail's 64..132): 64x64 tiles, measured 10-20 % faster
         launch_big<2, 2>(ta, tb, dim3((N + 127) / 128, (M + 127) / 128), st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
     } else {
         launch_big<1, 1>(ta, tb, dim3((N + 63) / 64, (M + 63) / 64), st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
