@@ -251,6 +251,31 @@ int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, 
 
 
 // =============================================================================================
+// format_data (reference src/dagr/utils/buffers.py:33-44) for the events of a loader batch in ONE launch:
+//   pos f32[N,3] = cat(pos i16[N,2], t i32[N]) / (W, H, T)   (torch: integer cat, then true division = both operands
+//   converted to fp32 and divided, IEEE round-to-nearest),   x f32[N] = float(x i8[N]).
+__global__ void k_format_events(const short* __restrict__ pos, const int* __restrict__ t, const signed char* __restrict__ x, int N,
+                                const long long* __restrict__ width, const long long* __restrict__ height,
+                                const long long* __restrict__ time_window, float* __restrict__ pos_out, float* __restrict__ x_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float Wf = (float)width[0], Hf = (float)height[0], Tf = (float)time_window[0];     // the batch's own (device) scalars: no host sync
+    pos_out[3 * i] = __fdiv_rn((float)pos[2 * i], Wf);
+    pos_out[3 * i + 1] = __fdiv_rn((float)pos[2 * i + 1], Hf);
+    pos_out[3 * i + 2] = __fdiv_rn((float)t[i], Tf);
+    x_out[i] = (float)x[i];
+}
+
+extern "C" int eventad_format_events(const int16_t* pos, const int32_t* t, const int8_t* x, int N, const int64_t* width,
+                                     const int64_t* height, const int64_t* time_window, float* pos_out, float* x_out, void* stream) {
+    if (!pos || !t || !x || !pos_out || !x_out || N < 0 || !width || !height || !time_window) return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    hipLaunchKernelGGL(k_format_events, dim3(evad_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream, (const short*)pos, t,
+                       (const signed char*)x, N, (const long long*)width, (const long long*)height, (const long long*)time_window, pos_out, x_out);
+    return evad_last_error();
+}
+
+// =============================================================================================
 // (B) native path: counting sort by pixel + ELL edge search
 // =============================================================================================
 // denormalize_pos (reference ev_tgn.py:11-16): (int)(W*pos + 1e-3) with separate fp32 mul and add.

@@ -46,6 +46,13 @@ int eventad_fill_edges(const int32_t* batch, const int32_t* pos, const int32_t* 
 /* spiral.h:1-15 as a table; dxdy is HOST memory int16[(2r+1)^2][2]; returns the number of steps. */
 int eventad_spiral_offsets(int radius, int16_t* dxdy);
 
+/* ---- (A') format_data for the events of a loader batch (src/dagr/utils/buffers.py:33-44) in one launch:
+ * pos_out f32[N,3] = (pos_x / W, pos_y / H, t / T) with the int -> fp32 conversion and IEEE division torch applies,
+ * x_out f32[N] = float(x).  Inputs as collated by the loader: pos i16[N,2], t i32[N], x i8[N]; width / height /
+ * time_window are the batch's i64 DEVICE tensors (element 0 is used, as the reference does): no host sync. */
+int eventad_format_events(const int16_t* pos, const int32_t* t, const int8_t* x, int N, const int64_t* width,
+                          const int64_t* height, const int64_t* time_window, float* pos_out, float* x_out, void* stream);
+
 /* ---- (B) native graph build: replaces EV_TGN.forward + SlidingWindowGraph.forward ------------- */
 /* (ev_tgn.py:39-58, ev_graph.py:62-103, graph/utils.py:6-23) for one fresh batch.
  * eventad_sort_events: denormalise (ev_tgn.py:11-16), counting-sort the events by pixel, and emit
