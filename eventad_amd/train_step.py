@@ -213,10 +213,13 @@ class TrainStep:
         self.graph = None
         return self._gb, self._gh
 
-    def replay_dual(self):
+    def replay_dual(self, join=True):
+        """join=False: the two streams are coupled only by the feature hand-over events (no per-step barrier with the
+        caller's stream); call once with join=True -- or synchronise -- before reading the results."""
         main = torch.cuda.current_stream()
         sg, sh = self._sg, self._sh
-        sg.wait_stream(main); sh.wait_stream(main)
+        if join:
+            sg.wait_stream(main); sh.wait_stream(main)
         with torch.cuda.stream(sh):
             sh.wait_event(self._ev_b)
             self._feats_cur.copy_(self._feats_next)
@@ -226,7 +229,8 @@ class TrainStep:
             sg.wait_event(self._ev_c)
             self._gb.replay()
             self._ev_b.record(sg)
-        main.wait_stream(sg); main.wait_stream(sh)
+        if join:
+            main.wait_stream(sg); main.wait_stream(sh)
         return self._g_loss, self._g_norm
 
     # ---- three-stage pipeline: front(batch k+2) || tail + ROI(batch k+1) || head update(batch k).
