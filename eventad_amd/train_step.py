@@ -142,13 +142,18 @@ class TrainStep:
     # concurrently and then hands feats_next over.  Every batch still gets exactly one backbone pass and one
     # head update with the weights left by the previous batch -- results are identical to step(); the
     # launch-bound head chain and the backbone's small kernels simply share the 256 CUs.
+    _head_priority = False
+
     def prime(self, data):
         """Fill the pipeline: features of the first batch."""
         with torch.no_grad():
             f = self.model.extract_features(data, frames=(1,))
         if getattr(self, "_feats_cur", None) is None or self._feats_cur.shape != f.shape:
             self._feats_cur = torch.empty_like(f)
-            self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream()
+            # the head's launches are tiny and latency-bound: on a high-priority stream their workgroups get the next free
+            # slots while the backbone's wide kernels run (+2 % with two single-branch graphs; inside ONE two-branch
+            # graph a priority stream is 2x SLOWER on this runtime, so capture() uses it only when asked)
+            self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream(priority=-1 if self._head_priority else 0)
         self._feats_cur.copy_(f)
 
     def pipelined_step(self, data_cur, labels_cur=None, data_next=None):
@@ -184,6 +189,8 @@ class TrainStep:
         if labels is None:
             labels = data.bbox[:, 4]
         data_next = data_next or data
+        self._head_priority = True
+        self._feats_cur = None                                 # (re)create the streams with the head's priority
         self.prime(data)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
