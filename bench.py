@@ -165,7 +165,10 @@ def main():
         ts.step(data)
     if use_graph:
         try:
-            if pipelined and a.pipeline_stages == 2 and not a.single_graph:
+            if pipelined and a.pipeline_stages == 3 and not a.single_graph:
+                ts.capture_triple(data)
+                run = lambda: ts.replay_triple(join=False)
+            elif pipelined and a.pipeline_stages == 2 and not a.single_graph:
                 ts.capture_dual(data)                          # backbone graph || head graph on two streams
                 run = lambda: ts.replay_dual(join=False)   # event-coupled streams; the timed region ends with a device-wide sync
             else:

@@ -284,6 +284,85 @@ class TrainStep:
         self._feats_cur.copy_(feats_next)
         return loss, norm
 
+    # ---- the three-stage pipeline as THREE single-branch graphs on three event-coupled streams:
+    #     stream A: front(k+2)                      -> hand-off set 0
+    #     stream B: hand 1 <- hand 0; tail + ROI(k+1) -> feats_next        (high priority)
+    #     stream H: feats_cur <- feats_next; head update(k)                  (high priority)
+    def capture_triple(self, data, labels=None, warmup=2):
+        assert self.native, "graph capture is for the GPU path"
+        if labels is None:
+            labels = data.bbox[:, 4]
+        net = self.model.dagr_model.backbone
+        self.prime3(data)
+        self._s3 = (torch.cuda.Stream(), torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.pipelined_step3(data, labels, data, data)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        hands = net._native.ws["hand"]
+        self._retired = getattr(self, "_retired", []) + [g for g in getattr(self, "_g3", ()) if g is not None]
+        ga, gb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                net.front(data)
+            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                out4 = net.tail(hands[1])[0][1]
+                self._feats_next = self.model.roi_features(out4, data, frames=(1,))
+            with torch.cuda.graph(gh, capture_error_mode="thread_local"):
+                loss, logits, valid, targets = self.model._head_native(self._feats_cur, data, labels, lean=True)
+                self.nh.backward()
+                if self.world > 1:
+                    dist.all_reduce(self.nh.grads, op=dist.ReduceOp.SUM, group=self.group)
+                norm = self.nh.optimizer_step()
+        self._g3, self._g_loss, self._g_norm = (ga, gb, gh), loss, norm
+        self._ev3 = {k: torch.cuda.Event() for k in ("a", "h", "b", "c")}
+        sa, sb, sh = self._s3
+        main = torch.cuda.current_stream()
+        for s_ in (sa, sb, sh):
+            s_.wait_stream(main)
+        # state of a primed pipeline: hand 0 = front(batch), feats_next = tail(hand 1) of the batch before it
+        with torch.cuda.stream(sa):
+            ga.replay(); self._ev3["a"].record(sa)
+        with torch.cuda.stream(sb):
+            gb.replay(); self._ev3["b"].record(sb)
+        with torch.cuda.stream(sh):
+            self._ev3["c"].record(sh)
+        self.graph = None
+        return self._g3
+
+    def replay_triple(self, join=False):
+        ga, gb, gh = self._g3
+        sa, sb, sh = self._s3
+        ev = self._ev3
+        net = self.model.dagr_model.backbone
+        hands = net._native.ws["hand"]
+        main = torch.cuda.current_stream()
+        if join:
+            for s_ in (sa, sb, sh):
+                s_.wait_stream(main)
+        with torch.cuda.stream(sh):                            # head(k): features of tail(k), handed over first
+            sh.wait_event(ev["b"])
+            self._feats_cur.copy_(self._feats_next)
+            ev["c"].record(sh)
+            gh.replay()
+        with torch.cuda.stream(sb):                            # tail(k+1): level-0 graph of front(k+1), handed over first
+            sb.wait_event(ev["a"]); sb.wait_event(ev["c"])
+            hands[1].flat.copy_(hands[0].flat)
+            ev["h"].record(sb)
+            gb.replay()
+            ev["b"].record(sb)
+        with torch.cuda.stream(sa):                            # front(k+2)
+            sa.wait_event(ev["h"])
+            ga.replay()
+            ev["a"].record(sa)
+        if join:
+            for s_ in (sa, sb, sh):
+                main.wait_stream(s_)
+        return self._g_loss, self._g_norm
+
     def step_from_feats(self, feats, data, labels=None):
         if labels is None:
             labels = data.bbox[:, 4]

@@ -116,7 +116,7 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
     from eventad_amd.train_step import TrainStep
     W = H = 64; B = 3; n = 3000
     results = []
-    for mode in ("sequential", "pipelined", "graph", "graph3", "dual", "dual_nojoin"):
+    for mode in ("sequential", "pipelined", "graph", "graph3", "dual", "dual_nojoin", "triple"):
         args, model, sd, head_sd, raw, data = _build(W, H, B, n)
         model.eval()
         ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
@@ -127,6 +127,10 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
             ts.prime(data)
             for _ in range(4):
                 loss, norm = ts.pipelined_step(data)
+        elif mode == "triple":                               # three graphs on three streams: prime 1 + warm-up 1 ...
+            ts.capture_triple(data, warmup=1)
+            for _ in range(3):                               # ... + 3 replays = 4 updates
+                loss, norm = ts.replay_triple()
         elif mode in ("dual", "dual_nojoin"):
             ts.capture_dual(data, warmup=1)                  # two single-branch graphs on two streams
             for _ in range(3):
