@@ -278,9 +278,12 @@ struct TProb {
 struct TGroup { TProb p[TG_MAXP]; int n; };
 
 __global__ __launch_bounds__(256) void k_tile_gemm(TGroup g) {
-    __shared__ float As[4][64][33];
-    __shared__ float Bs[4][64][33];
-    __shared__ float Red[3][32][33];
+    // 33.8 KB of LDS: a wave stages its 64-deep K chunk as two 32-deep halves through its own [32][33] A and B buffers
+    // (all 16 loads of the chunk are issued first; a wave's LDS traffic is ordered, so no barrier between the halves),
+    // and the cross-wave reduction re-uses the staging memory.  With 80 KB (whole chunk staged at once) a workgroup of
+    // this kernel displaced one of the two layer-1 convolution workgroups of its CU whenever the two streams overlapped.
+    __shared__ float Stage[8][32][33];
+    float (*Red)[32][33] = (float (*)[32][33])Stage;       // [3][32][33], valid after the barrier that ends the MFMA phase
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < TG_MAXP; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].block0) pi = i;
@@ -289,55 +292,47 @@ __global__ __launch_bounds__(256) void k_tile_gemm(TGroup g) {
     const int per_k = P.tiles_m * P.tiles_n;
     const int kg = local / per_k, rem = local % per_k, mt = rem / P.tiles_n, nt = rem % P.tiles_n;
     const int m0 = mt * 32, n0 = nt * 32, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float (*as)[33] = As[wave];
-    float (*bs)[33] = Bs[wave];
+    float (*as)[33] = Stage[wave];
+    float (*bs)[33] = Stage[4 + wave];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     {   // one round: this workgroup's 4 K chunks (K > 256 is spread over several workgroups per tile)
         const int ks = kg * 4 + wave, k0 = ks * 64;
         const bool live = ks < P.ksplit;
-        if (P.ta) {                                         // A stored [K,M]
+        float4 ra[2][4], rb[2][4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int f = lane + 64 * i, kr = f >> 3, mq = (f & 7) * 4, gk = k0 + kr, gm = m0 + mq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live && gk < P.K) v = ld4_guard(P.A + (size_t)gk * P.lda + gm, gm, P.M);
-                as[kr][mq] = v.x; as[kr][mq + 1] = v.y; as[kr][mq + 2] = v.z; as[kr][mq + 3] = v.w;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = lane + 64 * i, hi = f >> 3, lo = (f & 7) * 4, kb = k0 + 32 * h;
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+                if (live) {
+                    if (P.ta) { if (kb + hi < P.K) va = ld4_guard(P.A + (size_t)(kb + hi) * P.lda + m0 + lo, m0 + lo, P.M); }      // A stored [K,M]
+                    else      { if (m0 + hi < P.M) va = ld4_guard(P.A + (size_t)(m0 + hi) * P.lda + kb + lo, kb + lo, P.K); }      // A stored [M,K]
+                    if (P.tb) { if (n0 + hi < P.N) vb = ld4_guard(P.B + (size_t)(n0 + hi) * P.ldb + kb + lo, kb + lo, P.K); }      // B stored [N,K]
+                    else      { if (kb + hi < P.K) vb = ld4_guard(P.B + (size_t)(kb + hi) * P.ldb + n0 + lo, n0 + lo, P.N); }      // B stored [K,N]
+                }
+                ra[h][i] = va; rb[h][i] = vb;
             }
-        } else {                                            // A stored [M,K]
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int f = lane + 64 * i, row = f >> 4, kq = (f & 15) * 4, gk = k0 + kq, gm = m0 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live && gm < P.M) v = ld4_guard(P.A + (size_t)gm * P.lda + gk, gk, P.K);
-                as[kq][row] = v.x; as[kq + 1][row] = v.y; as[kq + 2][row] = v.z; as[kq + 3][row] = v.w;
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = lane + 64 * i, hi = f >> 3, lo = (f & 7) * 4;
+                const float4 va = ra[h][i], vb = rb[h][i];
+                if (P.ta) { as[hi][lo] = va.x; as[hi][lo + 1] = va.y; as[hi][lo + 2] = va.z; as[hi][lo + 3] = va.w; }
+                else      { as[lo][hi] = va.x; as[lo + 1][hi] = va.y; as[lo + 2][hi] = va.z; as[lo + 3][hi] = va.w; }
+                if (P.tb) { bs[lo][hi] = vb.x; bs[lo + 1][hi] = vb.y; bs[lo + 2][hi] = vb.z; bs[lo + 3][hi] = vb.w; }
+                else      { bs[hi][lo] = vb.x; bs[hi][lo + 1] = vb.y; bs[hi][lo + 2] = vb.z; bs[hi][lo + 3] = vb.w; }
             }
-        }
-        if (P.tb) {                                         // B stored [N,K]
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int f = lane + 64 * i, col = f >> 4, kq = (f & 15) * 4, gn = n0 + col, gk = k0 + kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live && gn < P.N) v = ld4_guard(P.B + (size_t)gn * P.ldb + gk, gk, P.K);
-                bs[kq][col] = v.x; bs[kq + 1][col] = v.y; bs[kq + 2][col] = v.z; bs[kq + 3][col] = v.w;
-            }
-        } else {                                            // B stored [K,N]
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int f = lane + 64 * i, kr = f >> 3, nq = (f & 7) * 4, gk = k0 + kr, gn = n0 + nq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live && gk < P.K) v = ld4_guard(P.B + (size_t)gk * P.ldb + gn, gn, P.N);
-                bs[kr][nq] = v.x; bs[kr][nq + 1] = v.y; bs[kr][nq + 2] = v.z; bs[kr][nq + 3] = v.w;
+            for (int kk = 0; kk < 32; kk += 2) {
+                const int kr = kk + (lane >> 5), c = lane & 31;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kr][c], bs[kr][c], acc, 0, 0, 0);
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 64; kk += 2) {
-            int kr = kk + (lane >> 5), c = lane & 31;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kr][c], bs[kr][c], acc, 0, 0, 0);
-        }
-        __syncthreads();
+        __syncthreads();                                    // every wave is done with its staging memory: Red may overwrite it
     }
     if (wave > 0) {
 #pragma unroll
