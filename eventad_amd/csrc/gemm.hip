@@ -278,12 +278,12 @@ struct TProb {
 struct TGroup { TProb p[TG_MAXP]; int n; };
 
 __global__ __launch_bounds__(256) void k_tile_gemm(TGroup g) {
-    // 33.8 KB of LDS: a wave stages its 64-deep K chunk as two 32-deep halves through its own [32][33] A and B buffers
-    // (all 16 loads of the chunk are issued first; a wave's LDS traffic is ordered, so no barrier between the halves),
-    // and the cross-wave reduction re-uses the staging memory.  With 80 KB (whole chunk staged at once) a workgroup of
-    // this kernel displaced one of the two layer-1 convolution workgroups of its CU whenever the two streams overlapped.
-    __shared__ float Stage[8][32][33];
-    float (*Red)[32][33] = (float (*)[32][33])Stage;       // [3][32][33], valid after the barrier that ends the MFMA phase
+    // 16.9 KB of LDS: a wave stages its 64-deep K chunk as four 16-deep quarters through its own [16][33] A and B
+    // buffers (all 16 loads of the chunk are issued first; a wave's LDS traffic is ordered, so no barrier between the
+    // quarters), and the cross-wave reduction re-uses the staging memory.  With 80 KB (whole chunk staged at once) a
+    // workgroup of this kernel displaced a layer-1 convolution workgroup of its CU whenever the two streams overlapped.
+    __shared__ float Stage[8][16][33];
+    float (*Red)[32][33] = (float (*)[32][33])Stage;       // [3][32][33] = 12.7 KB <= 16.9 KB, valid after the barrier below
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < TG_MAXP; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].block0) pi = i;
@@ -300,34 +300,38 @@ __global__ __launch_bounds__(256) void k_tile_gemm(TGroup g) {
     {   // one round: this workgroup's 4 K chunks (K > 256 is spread over several workgroups per tile)
         const int ks = kg * 4 + wave, k0 = ks * 64;
         const bool live = ks < P.ksplit;
-        float4 ra[2][4], rb[2][4];
+        float4 ra[4][2], rb[4][2];
+        // quarter q covers k0 + 16q .. +15.  k-major operands ([K,M] / [K,N]): 16 k-rows x 8 float4; row-major
+        // operands ([M,K] / [N,K]): 32 rows x 4 float4 -- 128 float4 per operand per quarter = 2 per lane
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = lane + 64 * i, hi = f >> 3, lo = (f & 7) * 4, kb = k0 + 32 * h;
+            for (int i = 0; i < 2; ++i) {
+                const int f = lane + 64 * i, kb = k0 + 16 * q;
+                const int kr = f >> 3, kl = (f & 7) * 4;    // k-major: k row, 4 consecutive m/n
+                const int rw = f >> 2, rl = (f & 3) * 4;    // row-major: m/n row, 4 consecutive k
                 float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
                 if (live) {
-                    if (P.ta) { if (kb + hi < P.K) va = ld4_guard(P.A + (size_t)(kb + hi) * P.lda + m0 + lo, m0 + lo, P.M); }      // A stored [K,M]
-                    else      { if (m0 + hi < P.M) va = ld4_guard(P.A + (size_t)(m0 + hi) * P.lda + kb + lo, kb + lo, P.K); }      // A stored [M,K]
-                    if (P.tb) { if (n0 + hi < P.N) vb = ld4_guard(P.B + (size_t)(n0 + hi) * P.ldb + kb + lo, kb + lo, P.K); }      // B stored [N,K]
-                    else      { if (kb + hi < P.K) vb = ld4_guard(P.B + (size_t)(kb + hi) * P.ldb + n0 + lo, n0 + lo, P.N); }      // B stored [K,N]
+                    if (P.ta) { if (kb + kr < P.K) va = ld4_guard(P.A + (size_t)(kb + kr) * P.lda + m0 + kl, m0 + kl, P.M); }
+                    else      { if (m0 + rw < P.M) va = ld4_guard(P.A + (size_t)(m0 + rw) * P.lda + kb + rl, kb + rl, P.K); }
+                    if (P.tb) { if (n0 + rw < P.N) vb = ld4_guard(P.B + (size_t)(n0 + rw) * P.ldb + kb + rl, kb + rl, P.K); }
+                    else      { if (kb + kr < P.K) vb = ld4_guard(P.B + (size_t)(kb + kr) * P.ldb + n0 + kl, n0 + kl, P.N); }
                 }
-                ra[h][i] = va; rb[h][i] = vb;
+                ra[q][i] = va; rb[q][i] = vb;
             }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = lane + 64 * i, hi = f >> 3, lo = (f & 7) * 4;
-                const float4 va = ra[h][i], vb = rb[h][i];
-                if (P.ta) { as[hi][lo] = va.x; as[hi][lo + 1] = va.y; as[hi][lo + 2] = va.z; as[hi][lo + 3] = va.w; }
-                else      { as[lo][hi] = va.x; as[lo + 1][hi] = va.y; as[lo + 2][hi] = va.z; as[lo + 3][hi] = va.w; }
-                if (P.tb) { bs[lo][hi] = vb.x; bs[lo + 1][hi] = vb.y; bs[lo + 2][hi] = vb.z; bs[lo + 3][hi] = vb.w; }
-                else      { bs[hi][lo] = vb.x; bs[hi][lo + 1] = vb.y; bs[hi][lo + 2] = vb.z; bs[hi][lo + 3] = vb.w; }
+            for (int i = 0; i < 2; ++i) {
+                const int f = lane + 64 * i, kr = f >> 3, kl = (f & 7) * 4, rw = f >> 2, rl = (f & 3) * 4;
+                const float4 va = ra[q][i], vb = rb[q][i];
+                if (P.ta) { as[kr][kl] = va.x; as[kr][kl + 1] = va.y; as[kr][kl + 2] = va.z; as[kr][kl + 3] = va.w; }
+                else      { as[rl][rw] = va.x; as[rl + 1][rw] = va.y; as[rl + 2][rw] = va.z; as[rl + 3][rw] = va.w; }
+                if (P.tb) { bs[rl][rw] = vb.x; bs[rl + 1][rw] = vb.y; bs[rl + 2][rw] = vb.z; bs[rl + 3][rw] = vb.w; }
+                else      { bs[kr][kl] = vb.x; bs[kr][kl + 1] = vb.y; bs[kr][kl + 2] = vb.z; bs[kr][kl + 3] = vb.w; }
             }
 #pragma unroll
-            for (int kk = 0; kk < 32; kk += 2) {
+            for (int kk = 0; kk < 16; kk += 2) {
                 const int kr = kk + (lane >> 5), c = lane & 31;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kr][c], bs[kr][c], acc, 0, 0, 0);
             }
