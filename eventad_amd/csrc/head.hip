@@ -166,7 +166,10 @@ struct StepBwdGroup { StepBwdProb p[3]; int n; };
 template <int CH>
 __device__ __forceinline__ void step_bwd_body(const StepBwdProb& P) {
     constexpr int H = CH * 32;
-    __shared__ float s_da[NT], s_al[NT], s_c[NT][H + 1];
+    // s_c holds the per-row terms of d(attention w) for the column sums: the two rows of a wave are added in registers
+    // first, so 16 row pairs are staged (16 KB instead of 33 KB -- small enough to sit beside two layer-1 convolution
+    // workgroups on a CU when the two streams overlap)
+    __shared__ float s_da[NT], s_al[NT], s_c[NT / 2][H + 1];
     __shared__ int s_v[NT];
     const int tid = threadIdx.x, k = tid >> 5, c = tid & 31;
     if (tid < NT) { s_v[tid] = P.valid[tid]; s_al[tid] = P.alpha[tid]; }
@@ -206,7 +209,10 @@ __device__ __forceinline__ void step_bwd_body(const StepBwdProb& P) {
             if (P.dhn_out) dh += P.dhn_out[t];
             dspass = 0.f;
         }
-        s_c[k][j] = ds * th;
+        {
+            const float mine = ds * th, other = __shfl_xor(mine, 32, 64);        // rows k (even, low half-wave) and k+1
+            if (!(k & 1)) s_c[k >> 1][j] = mine + other;
+        }
         // GRU cell backward (see k_gru_cell_bwd)
         if (P.dx_part) {
             float dx = 0.f;
@@ -226,7 +232,7 @@ __device__ __forceinline__ void step_bwd_body(const StepBwdProb& P) {
     if (tid < H) {
         float acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < NT; ++q) acc += s_c[q][tid];
+        for (int q = 0; q < NT / 2; ++q) acc += s_c[q][tid];
         P.dw[tid] += acc;                                   // every problem of a launch owns its own dw accumulator
     }
 }
