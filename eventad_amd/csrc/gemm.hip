@@ -300,40 +300,49 @@ __global__ __launch_bounds__(256) void k_tile_gemm(TGroup g) {
     {   // one round: this workgroup's 4 K chunks (K > 256 is spread over several workgroups per tile)
         const int ks = kg * 4 + wave, k0 = ks * 64;
         const bool live = ks < P.ksplit;
-        float4 ra[4][2], rb[4][2];
         // quarter q covers k0 + 16q .. +15.  k-major operands ([K,M] / [K,N]): 16 k-rows x 8 float4; row-major
-        // operands ([M,K] / [N,K]): 32 rows x 4 float4 -- 128 float4 per operand per quarter = 2 per lane
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int f = lane + 64 * i, kb = k0 + 16 * q;
-                const int kr = f >> 3, kl = (f & 7) * 4;    // k-major: k row, 4 consecutive m/n
-                const int rw = f >> 2, rl = (f & 3) * 4;    // row-major: m/n row, 4 consecutive k
-                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-                if (live) {
-                    if (P.ta) { if (kb + kr < P.K) va = ld4_guard(P.A + (size_t)(kb + kr) * P.lda + m0 + kl, m0 + kl, P.M); }
-                    else      { if (m0 + rw < P.M) va = ld4_guard(P.A + (size_t)(m0 + rw) * P.lda + kb + rl, kb + rl, P.K); }
-                    if (P.tb) { if (n0 + rw < P.N) vb = ld4_guard(P.B + (size_t)(n0 + rw) * P.ldb + kb + rl, kb + rl, P.K); }
-                    else      { if (kb + kr < P.K) vb = ld4_guard(P.B + (size_t)(kb + kr) * P.ldb + n0 + kl, n0 + kl, P.N); }
-                }
-                ra[q][i] = va; rb[q][i] = vb;
+        // operands ([M,K] / [N,K]): 32 rows x 4 float4 -- 128 float4 per operand per quarter = 2 per lane.
+        // Two halves of 8 loads: the second half is issued once the first sits in LDS, under the first half's MFMAs --
+        // 32 load registers live at a time instead of 64, so a wave of this kernel (~60 VGPRs) also fits on a SIMD that
+        // the backbone's row scan (112 x 4) or pool (88 x 5) has filled up to the last 64-72 registers.
+        float4 ra[2][2], rb[2][2];
+        auto fetch = [&](int q, int i, float4& va, float4& vb) {
+            const int f = lane + 64 * i, kb = k0 + 16 * q;
+            const int kr = f >> 3, kl = (f & 7) * 4;        // k-major: k row, 4 consecutive m/n
+            const int rw = f >> 2, rl = (f & 3) * 4;        // row-major: m/n row, 4 consecutive k
+            va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va;
+            if (live) {
+                if (P.ta) { if (kb + kr < P.K) va = ld4_guard(P.A + (size_t)(kb + kr) * P.lda + m0 + kl, m0 + kl, P.M); }
+                else      { if (m0 + rw < P.M) va = ld4_guard(P.A + (size_t)(m0 + rw) * P.lda + kb + rl, kb + rl, P.K); }
+                if (P.tb) { if (n0 + rw < P.N) vb = ld4_guard(P.B + (size_t)(n0 + rw) * P.ldb + kb + rl, kb + rl, P.K); }
+                else      { if (kb + kr < P.K) vb = ld4_guard(P.B + (size_t)(kb + kr) * P.ldb + n0 + kl, n0 + kl, P.N); }
             }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int f = lane + 64 * i, kr = f >> 3, kl = (f & 7) * 4, rw = f >> 2, rl = (f & 3) * 4;
-                const float4 va = ra[q][i], vb = rb[q][i];
-                if (P.ta) { as[kr][kl] = va.x; as[kr][kl + 1] = va.y; as[kr][kl + 2] = va.z; as[kr][kl + 3] = va.w; }
-                else      { as[rl][rw] = va.x; as[rl + 1][rw] = va.y; as[rl + 2][rw] = va.z; as[rl + 3][rw] = va.w; }
-                if (P.tb) { bs[rl][rw] = vb.x; bs[rl + 1][rw] = vb.y; bs[rl + 2][rw] = vb.z; bs[rl + 3][rw] = vb.w; }
-                else      { bs[kr][kl] = vb.x; bs[kr][kl + 1] = vb.y; bs[kr][kl + 2] = vb.z; bs[kr][kl + 3] = vb.w; }
-            }
+        };
+        auto stage = [&](int i, const float4& va, const float4& vb) {
+            const int f = lane + 64 * i, kr = f >> 3, kl = (f & 7) * 4, rw = f >> 2, rl = (f & 3) * 4;
+            if (P.ta) { as[kr][kl] = va.x; as[kr][kl + 1] = va.y; as[kr][kl + 2] = va.z; as[kr][kl + 3] = va.w; }
+            else      { as[rl][rw] = va.x; as[rl + 1][rw] = va.y; as[rl + 2][rw] = va.z; as[rl + 3][rw] = va.w; }
+            if (P.tb) { bs[rl][rw] = vb.x; bs[rl + 1][rw] = vb.y; bs[rl + 2][rw] = vb.z; bs[rl + 3][rw] = vb.w; }
+            else      { bs[kr][kl] = vb.x; bs[kr][kl + 1] = vb.y; bs[kr][kl + 2] = vb.z; bs[kr][kl + 3] = vb.w; }
+        };
+        auto mfma16 = [&]() {
 #pragma unroll
             for (int kk = 0; kk < 16; kk += 2) {
                 const int kr = kk + (lane >> 5), c = lane & 31;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kr][c], bs[kr][c], acc, 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fetch(2 * half + qq, i, ra[qq][i], rb[qq][i]);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) stage(i, ra[qq][i], rb[qq][i]);
+                mfma16();
             }
         }
         __syncthreads();                                    // every wave is done with its staging memory: Red may overwrite it
