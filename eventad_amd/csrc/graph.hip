@@ -570,7 +570,7 @@ __device__ __forceinline__ int ell_exact_walk(const int2* __restrict__ ev2, cons
 }
 
 template <int R, bool MARK>
-__global__ __launch_bounds__(256) void k_build_ell_rowscan(const int2* __restrict__ ev2, const int* __restrict__ key_s,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_build_ell_rowscan(const int2* __restrict__ ev2, const int* __restrict__ key_s,
                                                            const unsigned* __restrict__ start, const unsigned* flags_in, int N,
                                                            int W, int H, int steps, int Q, int dt_max, int* __restrict__ ell_src,
                                                            uint16_t* __restrict__ ell_step, int* __restrict__ deg,
