@@ -569,6 +569,8 @@ __device__ __forceinline__ int ell_exact_walk(const int2* __restrict__ ev2, cons
     return nn;
 }
 
+// waves_per_eu(5,5) is a register cap (<= 96 VGPRs; the kernel needs 86 without spilling, 112 uncapped): its LDS allows 4
+// waves per SIMD anyway, and 4 x 86 leaves room for a wave of the head's kernels on the same SIMD when the streams overlap.
 template <int R, bool MARK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_build_ell_rowscan(const int2* __restrict__ ev2, const int* __restrict__ key_s,
                                                            const unsigned* __restrict__ start, const unsigned* flags_in, int N,
