@@ -237,7 +237,9 @@ __device__ __forceinline__ void step_bwd_body(const StepBwdProb& P) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k_step_bwd(StepBwdGroup g) {
+// <= 64 VGPRs (no spills): a 16-wave workgroup then needs 256 registers per SIMD -- what ONE retiring layer-1 convolution
+// workgroup frees -- instead of waiting for both convolution workgroups of a CU to drain
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_step_bwd(StepBwdGroup g) {
     const StepBwdProb& P = g.p[blockIdx.x];
     if (P.H == 256) step_bwd_body<8>(P); else step_bwd_body<1>(P);
 }
