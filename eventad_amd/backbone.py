@@ -92,8 +92,9 @@ class NativeBackbone:
 
     # ---------------------------------------------------------------- workspace
     def _alloc(self, N, B):
-        if self._ws_key == (N, B):
-            return self.ws
+        if self._ws_key is not None and self._ws_key[1] == B and N <= self._ws_key[0]:
+            return self.ws                                   # event-indexed arrays only need >= N rows: a loader's varying
+                                                             # batch sizes re-use the workspace of the largest batch seen
         g, dev = self.geom, self.device
         P = B * g.H * g.W
         K = g.max_neighbors

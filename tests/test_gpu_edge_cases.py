@@ -129,3 +129,26 @@ def test_full_size_c2_properties():
     out4 = res["out4"]
     n4 = int(out4["n_dev"].item())
     assert bool(torch.isfinite(out4["x"][:n4]).all()) and float(out4["x"][:n4].min()) >= 0  # ReLU output
+
+
+def test_workspace_of_a_larger_batch_is_reused_for_a_smaller_one():
+    """A loader's batches vary in size: after a large batch, a smaller one (same number of clips) must run in the same
+    workspace and give exactly what a fresh backbone gives."""
+    W = H = 64
+    from eventad_amd.backbone import NativeBackbone
+    from eventad_amd import weights
+    from oracle import dagr_ref
+    dev = torch.device("cuda:0")
+    big = dagr_ref.format_data(EventBatch.from_clips(_clips(W, H, [5000, 4000, 6000])))
+    small = dagr_ref.format_data(EventBatch.from_clips(_clips(W, H, [1200, 900, 2000])))
+    run = lambda nb, d: nb.forward(d.pos.to(dev), d.x.to(dev), d.batch.to(dev), 3, [m.to(dev) for m in d.image_feats])
+    nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
+    run(nb, big)
+    ws_id = id(nb.ws)
+    got = run(nb, small)
+    assert id(nb.ws) == ws_id                                                    # no re-allocation
+    n = int(got["out4"]["n_dev"].item())
+    x_reused = got["out4"]["x"][:n].clone()
+    fresh = run(NativeBackbone(weights.random_graph_state(), W, H, dev), small)
+    assert n == int(fresh["out4"]["n_dev"].item()) and torch.equal(x_reused, fresh["out4"]["x"][:n])
+    assert nb.check_flags() & ~1 == 0
