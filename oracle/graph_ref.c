@@ -14,9 +14,9 @@
  * across threads (each thread owns one FIFO column / one row of 16 edge slots),
  * so the serial loop gives the reference's result bit for bit.
  *
- * Parity pinning: the reference holds no tests or golden vectors for this path
- * and cannot be compiled here (needs CUDA + a GPU), so this file is pinned by
- * the hand-derived known-answer cases in tests/test_oracle_graph.py.
+ * PARITY UNPINNED w.r.t. reference outputs: the reference holds no tests or golden
+ * vectors for this path and cannot be compiled here (needs CUDA + a GPU); this file
+ * is pinned only by the hand-derived known-answer cases in tests/test_oracle_graph.py.
  */
 #include <stdint.h>
 

@@ -10,6 +10,8 @@ Hooks (net.py:46-47): features = raw `conv1` output (before bn1/relu), layer1..l
 each goes through its 1x1 `feature_dconv` (with bias).  The unused outputs
 (`output_dconv` on layer3/4, avgpool, fc) are not computed -- EventAD never reads them.
 State-dict keys follow torchvision's names under `backbone.net.module.`.
+PARITY UNPINNED w.r.t. reference outputs: torchvision is not installed here and the reference holds no fixtures for
+the trunk; the restated architecture is checked against shape/known-answer tests only (tests/test_oracle_ops.py).
 """
 import torch.nn.functional as F
 
