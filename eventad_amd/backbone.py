@@ -108,7 +108,7 @@ class NativeBackbone:
             front_arena=front_arena, counters=front_arena[:4], pix_count=front_arena[4:4 + P + 1],
             bitmap0=front_arena[4 + P + 1:].view(S0_, 3),
             key=i32(N), tq=i32(N), bev=i32(N), pix_start=i32(P + 1),
-            scan_tmp=i32(2 * (max(P, 1 << 16) // 2048 + 4)), sid_tmp=i32(N), sid=i32(N), long_list=i32(P),
+            scan_tmp=i32(2 * (max(P, 1 << 16) // 2048 + 4)), sid_tmp=i32(N), sid=i32(N),
             key_s=i32(N), ts_s=i32(N), ev2=i32(N, 2), posn_s=f32(N, 3), x0s=f32(N, 20),
             ell_src=i32(N, K), ell_step=torch.empty((N, K), dtype=torch.int16, device=dev), deg=i32(N),
             y1=f32(N, 16), y2=f32(N, 16), node_slot0=i32(N), node_vox0=i32(N), ovf_list=i32(max(N, 1)),
@@ -242,7 +242,7 @@ class NativeBackbone:
         L0_ = ws["levels"][0]
         self._c("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
              N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
-             ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["long_list"]), ptr(ws["counters"]),
+             ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["counters"]),
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
              ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), 3 * L0_.S, st)     # also clears counters, histogram, pool1 bitmap

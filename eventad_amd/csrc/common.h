@@ -22,6 +22,28 @@ static inline unsigned evad_blocks(long long n, int threads) {
     return (unsigned)(b < 1 ? 1 : b);
 }
 
+// Clear device memory with a fill KERNEL rather than a memset node: every entry point of this library may be recorded
+// into a hipGraph by its caller, and memset nodes recorded on this platform have replayed wrongly after the first replay.
+// p must be 4-byte aligned and bytes a multiple of 4.
+static __global__ void k_evad_zero(uint32_t* __restrict__ p, size_t words) {
+    const size_t head = min(words, (size_t)((16 - ((uintptr_t)p & 15)) & 15) >> 2);      // words before 16-byte alignment
+    const size_t vec = (words - head) >> 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint4* q = (uint4*)(p + head);
+    for (size_t k = i; k < vec; k += (size_t)gridDim.x * blockDim.x) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < head) p[i] = 0u;
+    const size_t tail0 = head + (vec << 2);
+    if (i < words - tail0) p[tail0 + i] = 0u;
+}
+static inline void evad_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    const size_t words = bytes >> 2;
+    size_t blocks = (words / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_evad_zero, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, words);
+}
+
 // order-preserving float <-> uint map so float max can use integer atomicMax (0 < every real)
 __device__ __forceinline__ unsigned evad_f2ord(float f) {
     unsigned u = __float_as_uint(f);

@@ -236,7 +236,7 @@ __global__ void k_scan_add(unsigned* __restrict__ out, const unsigned* __restric
 // out has n+1 entries (out[n] = grand total); tile_sums needs ceil(n/2048) entries.  in may alias out.
 // max_out (nullable): also max(in); tile_sums then needs 2*ceil(n/2048) entries.
 int evad_exclusive_scan_max(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, unsigned* max_out, hipStream_t st) {
-    if (n <= 0) { hipMemsetAsync(out, 0, sizeof(unsigned), st); return evad_last_error(); }
+    if (n <= 0) { evad_zero_async(out, sizeof(unsigned), st); return evad_last_error(); }
     int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     unsigned* tile_max = max_out ? tile_sums + tiles : nullptr;
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(SCAN_THREADS), 0, st, in, out, tile_sums, n, tile_max);
@@ -396,17 +396,17 @@ __global__ void k_gather_sorted(const int* __restrict__ sid_tmp, const unsigned*
     o[4] = make_float4(acc[3].w, px, py, 0.f);
 }
 
-extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const float* polarity,
-                                   const float* map0_nhwc, int map_h, int map_w,
-                                   int N, int B, int W, int H, int T,
-                                   int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
-                                   uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid, int32_t* long_list,
-                                   uint32_t* counters /* [0]=flags [1]=long_count */,
-                                   int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s,
-                                   float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
-                                   int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words, void* stream) {
+static int sort_events_impl(const float* pos, const int64_t* batch, const float* polarity,
+                            const float* map0_nhwc, int map_h, int map_w,
+                            int N, int B, int W, int H, int T,
+                            int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
+                            uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid,
+                            uint32_t* counters /* [0]=flags [2]=ovf count [3]=longest segment */,
+                            int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s,
+                            float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
+                            int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words, void* stream) {
     if (zero_tail_words < 0 || !pos || !batch || !polarity || !map0_nhwc || !key || !tq || !bev || !pix_count || !pix_start || !scan_tmp ||
-        !sid_tmp || !sid || !long_list || !counters || !key_s || !ts_s || !posn_s || !x0s ||
+        !sid_tmp || !sid || !counters || !key_s || !ts_s || !posn_s || !x0s ||
         N < 0 || B <= 0 || W <= 0 || H <= 0 || T <= 0 || map_h <= 0 || map_w <= 0)
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -414,11 +414,11 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     if (P >= (1ll << 31)) return EVAD_ERR_ARG;
     // counters (all four words: this is the first call of a step), the pixel histogram and -- when the caller laid
     // them out back to back -- `zero_tail_words` more words behind it (the step's other zero-initialised scratch)
-    if (counters + 4 == pix_count) hipMemsetAsync(counters, 0, sizeof(uint32_t) * (4 + P + 1 + (size_t)zero_tail_words), st);
+    if (counters + 4 == pix_count) evad_zero_async(counters, sizeof(uint32_t) * (4 + P + 1 + (size_t)zero_tail_words), st);
     else {
         if (zero_tail_words) return EVAD_ERR_ARG;
-        hipMemsetAsync(pix_count, 0, sizeof(uint32_t) * (P + 1), st);
-        hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), st);
+        evad_zero_async(pix_count, sizeof(uint32_t) * (P + 1), st);
+        evad_zero_async(counters, 4 * sizeof(uint32_t), st);
     }
     if (node_slot && (!px_to_cx || !py_to_cy || !ovf_list || !node_vox || nx <= 0 || ny <= 0 || vsx <= 0 || vsy <= 0)) return EVAD_ERR_ARG;
     if (N > 0)
@@ -432,6 +432,19 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
                        map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, (int2*)ev2, posn_s, x0s, vsx, vsy, nx, ny, nx * ny * (B + 1),
                        px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, counters);
     return evad_last_error();
+}
+
+extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const float* polarity,
+                                   const float* map0_nhwc, int map_h, int map_w,
+                                   int N, int B, int W, int H, int T,
+                                   int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
+                                   uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid, uint32_t* counters,
+                                   int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s,
+                                   float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
+                                   int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words, void* stream) {
+    return sort_events_impl(pos, batch, polarity, map0_nhwc, map_h, map_w, N, B, W, H, T, key, tq, bev, pix_count, pix_start, scan_tmp,
+                            sid_tmp, sid, counters, key_s, ts_s, ev2, posn_s, x0s, vsx, vsy, nx, ny, px_to_cx, py_to_cy, node_slot,
+                            node_vox, ovf_list, zero_tail_words, stream);
 }
 
 // Edge search over pixel CSR segments (semantics of ev_graph.cu:15-80, see header comment).
@@ -697,7 +710,7 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         (bitmap && (!node_slot || !node_vox || nx <= 0 || ny <= 0 || nx > 255 || ny > 255)))
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (bitmap && !bitmap_prezeroed) hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    if (bitmap && !bitmap_prezeroed) evad_zero_async(bitmap, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
     if (N == 0) return evad_last_error();
     int steps;
     if (ensure_spiral(radius_px, st, &steps)) return -2;

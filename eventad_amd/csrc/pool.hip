@@ -166,13 +166,13 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
     if (prezeroed) {}                                        // the caller zeroed the tables (one memset for all levels)
     else if ((const char*)sums == f0 + nf && (const char*)tsum == (const char*)sums + 16 * (size_t)S &&
         (const char*)cnt == (const char*)tsum + 8 * (size_t)S && (const char*)maxidx == (const char*)cnt + 4 * (size_t)S)
-        hipMemsetAsync(feat, 0, nf + 32 * (size_t)S, st);
+        evad_zero_async(feat, nf + 32 * (size_t)S, st);
     else {
-        hipMemsetAsync(feat, 0, nf, st);
-        hipMemsetAsync(sums, 0, sizeof(uint64_t) * 2 * (size_t)S, st);
-        hipMemsetAsync(tsum, 0, sizeof(double) * (size_t)S, st);
-        hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)S, st);
-        hipMemsetAsync(maxidx, 0, sizeof(int32_t) * (size_t)S, st);
+        evad_zero_async(feat, nf, st);
+        evad_zero_async(sums, sizeof(uint64_t) * 2 * (size_t)S, st);
+        evad_zero_async(tsum, sizeof(double) * (size_t)S, st);
+        evad_zero_async(cnt, sizeof(uint32_t) * (size_t)S, st);
+        evad_zero_async(maxidx, sizeof(int32_t) * (size_t)S, st);
     }
     if (n_max == 0) return evad_last_error();
     dim3 grid(evad_blocks(n_max, 16)), block(256);
@@ -658,7 +658,7 @@ extern "C" int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t
                                            void* stream) {
     if (!ell_src || !deg || !node_slot || !bitmap || !flags || N < 0 || nx <= 0 || ny <= 0 || B <= 0) return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    evad_zero_async(bitmap, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
     if (N > 0)
         hipLaunchKernelGGL(k_mark_ell, dim3(evad_blocks((long long)N * max_num_neighbors, 256)), dim3(256), 0, st, ell_src,
                            deg, node_slot, N, max_num_neighbors, nx, ny, bitmap, flags);
@@ -671,7 +671,7 @@ extern "C" int eventad_pool_edges_mark_csr(const uint32_t* rowptr, const int32_t
     if (!rowptr || !csr_src || !node_slot || !n_dev || !bitmap || !flags || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0)
         return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
+    if (!prezeroed) evad_zero_async(bitmap, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
     if (n_max > 0)
         hipLaunchKernelGGL(k_mark_csr, dim3(evad_blocks(n_max, 16)), dim3(256), 0, st, rowptr, csr_src, node_slot, n_max,
                            n_dev, nx, ny, bitmap, flags);

@@ -114,8 +114,6 @@ class TrainStep:
             body = lambda: self.pipelined_step(data, labels, data_next or data)
         else:
             body = lambda: self.step(data, labels)
-        if False:
-            pass
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -142,18 +140,14 @@ class TrainStep:
     # concurrently and then hands feats_next over.  Every batch still gets exactly one backbone pass and one
     # head update with the weights left by the previous batch -- results are identical to step(); the
     # launch-bound head chain and the backbone's small kernels simply share the 256 CUs.
-    _head_priority = False
-
     def prime(self, data):
         """Fill the pipeline: features of the first batch."""
         with torch.no_grad():
             f = self.model.extract_features(data, frames=(1,))
         if getattr(self, "_feats_cur", None) is None or self._feats_cur.shape != f.shape:
             self._feats_cur = torch.empty_like(f)
-            # the head's launches are tiny and latency-bound: on a high-priority stream their workgroups get the next free
-            # slots while the backbone's wide kernels run (+2 % with two single-branch graphs; inside ONE two-branch
-            # graph a priority stream is 2x SLOWER on this runtime, so capture() uses it only when asked)
-            self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream(priority=-1 if self._head_priority else 0)
+            # both streams at the default priority: work on streams of different priorities has hung on this platform
+            self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream()
         self._feats_cur.copy_(f)
 
     def pipelined_step(self, data_cur, labels_cur=None, data_next=None):
@@ -189,8 +183,6 @@ class TrainStep:
         if labels is None:
             labels = data.bbox[:, 4]
         data_next = data_next or data
-        self._head_priority = True
-        self._feats_cur = None                                 # (re)create the streams with the head's priority
         self.prime(data)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -286,15 +278,15 @@ class TrainStep:
 
     # ---- the three-stage pipeline as THREE single-branch graphs on three event-coupled streams:
     #     stream A: front(k+2)                      -> hand-off set 0
-    #     stream B: hand 1 <- hand 0; tail + ROI(k+1) -> feats_next        (high priority)
-    #     stream H: feats_cur <- feats_next; head update(k)                  (high priority)
+    #     stream B: hand 1 <- hand 0; tail + ROI(k+1) -> feats_next
+    #     stream H: feats_cur <- feats_next; head update(k)
     def capture_triple(self, data, labels=None, warmup=2):
         assert self.native, "graph capture is for the GPU path"
         if labels is None:
             labels = data.bbox[:, 4]
         net = self.model.dagr_model.backbone
         self.prime3(data)
-        self._s3 = (torch.cuda.Stream(), torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1))
+        self._s3 = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
