@@ -15,6 +15,8 @@
 //      an ELL adjacency (<=16 sources per destination, self edge first) in PIXEL-SORTED node
 //      numbering, so the layer-1 neighbour gathers that follow hit nearby rows.
 #include "common.h"
+#include <mutex>
+#include <stdio.h>
 
 // ------------------------------------------------------------------ spiral (reference spiral.h)
 // Offsets are generated on the host once per radius (eventad_spiral_offsets) and passed as a table.
@@ -445,6 +447,60 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
     return sort_events_impl(pos, batch, polarity, map0_nhwc, map_h, map_w, N, B, W, H, T, key, tq, bev, pix_count, pix_start, scan_tmp,
                             sid_tmp, sid, counters, key_s, ts_s, ev2, posn_s, x0s, vsx, vsy, nx, ny, px_to_cx, py_to_cy, node_slot,
                             node_vox, ovf_list, zero_tail_words, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same sort for callers that cannot allocate device memory (code under hipGraph capture, tight serving loops):
+// the pixel histogram, the scan's tile sums and the unordered scatter target live in ONE file-scope device array
+// instead of caller-provided workspace.  Every GPU the library runs on holds its own copy of the array (8.1 MiB) until
+// the process ends; its address on a device is looked up once per device with that device current.  All calls on
+// one GPU share the array, so calls that overlap on one GPU (different streams) race: serialise them.
+#define EVAD_STATIC_MAX_PIXELS (1 << 20)                 /* B*H*W  (C2: 8 x 256 x 256 = 524288) */
+#define EVAD_STATIC_MAX_EVENTS (1 << 20)                 /* N      (C2: 400000) */
+#define EVAD_STATIC_SCAN_WORDS (2 * (EVAD_STATIC_MAX_PIXELS / SCAN_TILE + 2))
+#define EVAD_STATIC_OFF_SCAN   (EVAD_STATIC_MAX_PIXELS + 64)                                   /* histogram: P + 1 words */
+#define EVAD_STATIC_OFF_SID    (EVAD_STATIC_OFF_SCAN + ((EVAD_STATIC_SCAN_WORDS + 63) / 64) * 64)
+#define EVAD_STATIC_WORDS      (EVAD_STATIC_OFF_SID + EVAD_STATIC_MAX_EVENTS)
+static __device__ __align__(256) uint32_t scratch[EVAD_STATIC_WORDS];
+#define EVAD_MAX_DEVICES 64
+static uint32_t* g_scratch_ptr[EVAD_MAX_DEVICES];        // device address of `scratch` per GPU (the symbol itself is no address)
+static std::mutex g_scratch_mutex;
+
+static int scratch_for_current_device(uint32_t** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EVAD_MAX_DEVICES) return -2;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return e != hipSuccess ? (int)e : -2;
+        g_scratch_ptr[dev] = (uint32_t*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int eventad_sort_events_static(const float* pos, const int64_t* batch, const float* polarity,
+                                          const float* map0_nhwc, int map_h, int map_w, int N, int B, int W, int H, int T,
+                                          int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_start, int32_t* sid,
+                                          uint32_t* counters, int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s,
+                                          float* x0s, float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx,
+                                          const int32_t* py_to_cy, int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list,
+                                          void* stream) {
+    if (N < 0 || B <= 0 || W <= 0 || H <= 0) return EVAD_ERR_ARG;
+    if ((long long)B * H * W > EVAD_STATIC_MAX_PIXELS || N > EVAD_STATIC_MAX_EVENTS) {
+        fprintf(stderr, "eventad_sort_events_static: B*H*W = %lld pixels / N = %d events exceed the static workspace "
+                        "(at most %d pixels and %d events); use eventad_sort_events with caller-owned workspace\n",
+                (long long)B * H * W, N, EVAD_STATIC_MAX_PIXELS, EVAD_STATIC_MAX_EVENTS);
+        return EVENTAD_ERR_TOO_LARGE;
+    }
+    uint32_t* ws = nullptr;
+    int rc = scratch_for_current_device(&ws);
+    if (rc) return rc;
+    // the histogram is cleared by sort_events_impl (fill kernel) on every call: the array keeps the last call's contents
+    return sort_events_impl(pos, batch, polarity, map0_nhwc, map_h, map_w, N, B, W, H, T, key, tq, bev, ws /* pix_count */, pix_start,
+                            ws + EVAD_STATIC_OFF_SCAN, (int32_t*)(ws + EVAD_STATIC_OFF_SID), sid, counters, key_s, ts_s, ev2, posn_s,
+                            x0s, vsx, vsy, nx, ny, px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, 0, stream);
 }
 
 // Edge search over pixel CSR segments (semantics of ev_graph.cu:15-80, see header comment).

@@ -27,6 +27,8 @@ extern "C" {
 #define EVENTAD_FLAG_POS_OUT_OF_FOV 2u
 #define EVENTAD_FLAG_POOL_WINDOW    4u
 #define EVENTAD_FLAG_T_OUT_OF_RANGE 8u
+/* return code of the *_static entry points when the input exceeds the library's fixed workspace */
+#define EVENTAD_ERR_TOO_LARGE (-3)
 
 /* ---- (A) reference-compatible graph builder: replaces pybind module ev_graph_cuda ------------- */
 /* insert_in_queue_cuda(indices, unique_coords, cumsum_counts, queue)   ev_graph.cu:241-276 (kernel :169-212)
@@ -77,6 +79,18 @@ int eventad_sort_events(const float* pos, const int64_t* batch, const float* pol
                         float* posn_s, float* x0s, float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx,
                         const int32_t* py_to_cy, int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words,
                         void* stream);
+/* eventad_sort_events without workspace arguments, for callers that cannot allocate device memory (code under hipGraph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs,
+ * outputs and results as eventad_sort_events; pix_count / scan_tmp / sid_tmp live in a fixed 8.1 MiB array inside the
+ * library (one copy per GPU, held until the process ends), so B*H*W <= 1048576 pixels and N <= 1048576 events:
+ * anything larger returns EVENTAD_ERR_TOO_LARGE (and says so on stderr).  Allocates nothing.  counters u32[4] stays
+ * caller-owned (the later stages read it).  All calls on one GPU share the array: calls that overlap on one GPU race. */
+int eventad_sort_events_static(const float* pos, const int64_t* batch, const float* polarity, const float* map0_nhwc,
+                               int map_h, int map_w, int N, int B, int W, int H, int T, int32_t* key, int32_t* tq,
+                               int32_t* bev, uint32_t* pix_start, int32_t* sid, uint32_t* counters, int32_t* key_s,
+                               int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s, float vsx, float vsy, int nx, int ny,
+                               const int32_t* px_to_cx, const int32_t* py_to_cy, int32_t* node_slot, int32_t* node_vox,
+                               int32_t* ovf_list, void* stream);
 /* eventad_build_ell: the edge search of ev_graph.cu:15-80 over the pixel CSR.  ELL adjacency in
  * pixel-sorted numbering: ell_src i32[N,K] (slot 0 = self edge), ell_step u16[N,K] (spiral step =
  * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
