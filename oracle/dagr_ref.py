@@ -127,6 +127,19 @@ def init_lut(weight, height, width, rx, Mx, ry=None, My=None):
     return lut.view((2 * rx + 1, 2 * ry + 1, cin, cout)), remap
 
 
+def lut_cells(weight, height, width, rx, Mx, ix, iy, ry=None, My=None):
+    """The LUT entries init_lut would hold at integer cells (ix, iy) -- i64[n] each, 0 <= ix <= 2rx, 0 <= iy <= 2ry --
+    evaluated on demand with the same fp32 expressions (spline_conv.py:27-35), so a geometry whose full LUT does not
+    fit in memory (14 GB per conv at 1280x720, layer 5) can still be checked.  -> f32[n, Cin, Cout]; equal bit for
+    bit to init_lut(...)[0][ix, iy] (tests/test_oracle_ops.py)."""
+    ry = ry or rx
+    My = My or Mx
+    ax = (ix - rx).float() / (2 * Mx * width) + 0.5
+    ay = (iy - ry).float() / (2 * My * height) + 0.5
+    bil_w, indices = spline_basis(torch.stack([ax, ay], 1))
+    return (bil_w[..., None, None] * weight[indices]).sum(1)
+
+
 def lut_indices(edge_attr, remap):
     """spline_conv.py:41-42: integer LUT cell of every edge."""
     dx = (edge_attr[:, 0] * remap[0, 0] + remap[0, -1] + 1e-3).long()
@@ -143,18 +156,33 @@ def spline_conv(x, edge_index, edge_attr, weight, root_weight, lut_params, heigh
                    [E,Cin,Cout] temporary of spline_conv.py:44 stays small), messages summed at
                    the destination in edge order.
     mode="grouped": same sum, edges grouped by LUT cell and multiplied as one matmul per cell
-                   (fp32 summation order differs; used for the timed CPU baseline)."""
+                   (fp32 summation order differs; used for the timed CPU baseline).
+    mode="ondemand": as "gather", but only the LUT cells some edge uses are evaluated (lut_cells) instead of
+                   building the whole table first: bit-identical to "gather", memory independent of the geometry."""
     rx, ry, M = lut_params
     n, cout = x.shape[0], weight.shape[2]
     out = torch.zeros((n, cout), dtype=x.dtype)
     E = edge_index.shape[1]
     if E > 0:
-        lut, remap = cached if cached is not None else init_lut(weight, height, width, rx=rx, Mx=M, ry=ry)
+        if mode == "ondemand":
+            lut = None
+            remap = torch.Tensor([[2 * M * width, 0, -M * width + rx], [0, 2 * M * height, -M * height + ry]])
+        else:
+            lut, remap = cached if cached is not None else init_lut(weight, height, width, rx=rx, Mx=M, ry=ry)
         dx, dy = lut_indices(edge_attr[:, :2], remap)
         assert int(dx.min()) >= 0 and int(dx.max()) <= 2 * rx, "LUT x index out of range"
         assert int(dy.min()) >= 0 and int(dy.max()) <= 2 * ry, "LUT y index out of range"
         src, dst = edge_index
-        if mode == "gather":
+        if mode == "ondemand":
+            cells, inv = torch.unique(dx * (2 * ry + 1) + dy, return_inverse=True)
+            for s in range(0, E, chunk):
+                e = slice(s, min(E, s + chunk))
+                used, loc = torch.unique(inv[e], return_inverse=True)         # LUT entries this chunk needs
+                cu = cells[used]
+                w = lut_cells(weight, height, width, rx, M, cu // (2 * ry + 1), cu % (2 * ry + 1), ry=ry)[loc]
+                msg = torch.einsum("nio,ni->no", w, x[src[e]])
+                out.index_add_(0, dst[e], msg)
+        elif mode == "gather":
             for s in range(0, E, chunk):
                 e = slice(s, min(E, s + chunk))
                 w = lut[dx[e], dy[e]]                               # [e, Cin, Cout]

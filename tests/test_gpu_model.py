@@ -36,11 +36,11 @@ def _build(W, H, B, n, live_cnn=False, seed=7):
     return args, model, sd, head_sd, raw, data
 
 
-def _oracle(sd, head_sd, raw, W, H, B, live_cnn=False, grads=False):
+def _oracle(sd, head_sd, raw, W, H, B, live_cnn=False, grads=False, mode="gather"):
     from oracle import dagr_ref, head_ref, resnet_ref
     d = dagr_ref.format_data(raw.clone())
     feats_img = resnet_ref.hook_module_forward(sd, d.image) if live_cnn else d.image_feats
-    o3, o4 = dagr_ref.backbone_forward(sd, d, dagr_ref.make_config(W, H, B), feats_img)
+    o3, o4 = dagr_ref.backbone_forward(sd, d, dagr_ref.make_config(W, H, B), feats_img, mode=mode)
     p = {k: v.clone().requires_grad_(grads) for k, v in head_sd.items()}
     feats = head_ref.roi_features(o4, d)
     loss, outs = head_ref.head_forward(p, feats, d, d.bbox[:, 4])
@@ -107,6 +107,28 @@ def test_live_cnn_branch_matches_oracle():
     o4, feats, loss, outs, _ = _oracle(sd, head_sd, raw, W, H, B, live_cnn=True)
     got = torch.cat([o for frame in outputs for o in frame], 0).cpu()
     want = torch.cat([o[2] for o in outs], 0).detach()
+    assert float((got - want).abs().max()) < 1e-3 and torch.equal(got.argmax(1), want.argmax(1))
+
+
+@pytest.mark.parametrize("W,H,B,n", [(64, 64, 1, 5000),          # the single-clip configuration: B = 1 takes the sampler's B' = max(B, 2) branch
+                                     (256, 256, 2, 200000)])     # 200k events per clip (dense windows, spiral-walk edge search) + the trunk at 256x256
+def test_live_cnn_configurations_match_oracle(W, H, B, n):
+    args, model, sd, head_sd, raw, data = _build(W, H, B, n, live_cnn=True)
+    from oracle import dagr_ref, resnet_ref
+    d = dagr_ref.format_data(raw.clone())
+    want = resnet_ref.hook_module_forward(sd, d.image)
+    got = model.dagr_model.backbone.net(data.image)
+    for g, w in zip(got, want):
+        g = g.permute(0, 3, 1, 2).cpu()
+        assert g.shape == w.shape
+        assert float((g - w).abs().max()) < 1e-3 * max(1.0, float(w.abs().max()))
+    model.eval()
+    with torch.no_grad():
+        losses, outputs, labels = model(data, data.bbox[:, 4])
+    o4, feats, loss, outs, _ = _oracle(sd, head_sd, raw, W, H, B, live_cnn=True, mode="ondemand")
+    got = torch.cat([o for frame in outputs for o in frame], 0).cpu()
+    want = torch.cat([o[2] for o in outs], 0).detach()
+    assert got.shape == want.shape and len(want) == 10 * B
     assert float((got - want).abs().max()) < 1e-3 and torch.equal(got.argmax(1), want.argmax(1))
 
 

@@ -112,3 +112,33 @@ def test_config_constants_match_survey():
     assert [(rx, ry) for rx, ry, _ in c2.lut[1:]] == [(10, 13), (19, 26), (37, 52), (74, 103)]
     c4 = R.make_config(1280, 720, 8)
     assert c4.lut[0][:2] == (13, 13) and abs(c4.eff_r - 0.021875) < 1e-12
+
+
+def test_on_demand_lut_cells_equal_the_full_lut():
+    """lut_cells (LUT entries evaluated per used cell) == init_lut, bit for bit, for every conv geometry at 256x256
+    (all cells; the layer-5 table is sampled), and spline_conv(mode="ondemand") == mode="gather"."""
+    from eventad_amd import weights
+    sd = weights.random_graph_state()
+    cfg = R.make_config(256, 256, 2)
+    g = torch.Generator().manual_seed(5)
+    for li, name in enumerate(["conv_block1.", "layer2.", "layer3.", "layer4.", "layer5."]):
+        rx, ry, M = cfg.lut[li]
+        w = sd["backbone." + name + "conv_block2.conv.weight"]
+        lut, _ = R.init_lut(w, 256, 256, rx=rx, Mx=M, ry=ry)
+        n = (2 * rx + 1) * (2 * ry + 1)
+        ix = torch.arange(2 * rx + 1).repeat_interleave(2 * ry + 1)
+        iy = torch.arange(2 * ry + 1).repeat(2 * rx + 1)
+        if n > 20000:
+            sel = torch.randperm(n, generator=g)[:20000]
+            ix, iy = ix[sel], iy[sel]
+        assert torch.equal(R.lut_cells(w, 256, 256, rx, M, ix, iy, ry=ry), lut[ix, iy]), name
+    # a small conv through both modes
+    rx, ry, M = cfg.lut[0]
+    n, E = 300, 2000
+    x = torch.randn(n, 16, generator=g)
+    ei = torch.randint(0, n, (2, E), generator=g)
+    attr = torch.randint(-rx, rx + 1, (E, 3), generator=g).float() / (2 * M * 256) + 0.5      # pixel offsets inside the radius
+    w, root = sd["backbone.conv_block1.conv_block2.conv.weight"], sd["backbone.conv_block1.conv_block2.conv.lin.weight"]
+    a = R.spline_conv(x, ei, attr, w, root, cfg.lut[0], 256, 256, mode="gather")
+    b = R.spline_conv(x, ei, attr, w, root, cfg.lut[0], 256, 256, mode="ondemand", chunk=512)
+    assert torch.equal(a, b)
