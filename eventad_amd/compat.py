@@ -62,14 +62,15 @@ def _ev_graph_module():
                      (queue, "queue")):
             _check(t, n)
         B, Q, H, W = queue.shape
-        call("eventad_insert_in_queue", ptr(indices), ptr(unique_coords.int()), ptr(cumsum_counts), ptr(queue),
+        coords = unique_coords.int()                         # held until after the launch (may be a fresh tensor)
+        call("eventad_insert_in_queue", ptr(indices), ptr(coords), ptr(cumsum_counts), ptr(queue),
              B, Q, H, W, unique_coords.shape[0], stream())
         return queue
 
     def insert_in_queue_single_cuda(indices, events, queue):
         B, Q, H, W = queue.shape
-        call("eventad_insert_in_queue_single", ptr(indices.int().contiguous()), ptr(events.int().contiguous()),
-             ptr(queue), B, Q, H, W, stream())
+        ids, ev = indices.int().contiguous(), events.int().contiguous()
+        call("eventad_insert_in_queue_single", ptr(ids), ptr(ev), ptr(queue), B, Q, H, W, stream())
         return queue
 
     m.fill_edges_cuda, m.insert_in_queue_cuda, m.insert_in_queue_single_cuda = \

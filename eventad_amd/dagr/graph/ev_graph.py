@@ -48,16 +48,20 @@ class SlidingWindowGraph:
             lin = pos[:, 0] + W * pos[:, 1] + W * H * batch
             s_lin, s_idx = torch.sort(lin, stable=True)
             uniq, counts = torch.unique_consecutive(s_lin, return_counts=True)
-            call("eventad_insert_in_queue", ptr(indices[s_idx].contiguous()), ptr(uniq.int().contiguous()),
-                 ptr(torch.cumsum(counts, 0).int().contiguous()), ptr(self.event_queue), B, Q, H, W, len(uniq), st)
+            # named tensors: a temporary would be freed -- and its block handed to the next temporary -- before the launch
+            sorted_ids, coords, ends = indices[s_idx].contiguous(), uniq.int().contiguous(), torch.cumsum(counts, 0).int().contiguous()
+            call("eventad_insert_in_queue", ptr(sorted_ids), ptr(coords), ptr(ends), ptr(self.event_queue), B, Q, H, W,
+                 len(uniq), st)
         else:
-            call("eventad_insert_in_queue_single", ptr(indices), ptr(pos.reshape(-1)), ptr(self.event_queue), B, Q, H, W, st)
+            flat = pos.reshape(-1)
+            call("eventad_insert_in_queue_single", ptr(indices), ptr(flat), ptr(self.event_queue), B, Q, H, W, st)
         K = self.max_num_neighbors * n
         if self.edge_buffer is None or self.edge_buffer.shape[1] < K:
             self.edge_buffer = torch.empty((2, K), dtype=torch.int64, device=self.device)
         buf = self.edge_buffer[:, :K].contiguous() if self.edge_buffer.shape[1] != K else self.edge_buffer
         buf.fill_(-1)
-        call("eventad_fill_edges", ptr(batch.contiguous()), ptr(pos), ptr(self.all_timestamps), ptr(self.event_queue),
+        batch = batch.contiguous()
+        call("eventad_fill_edges", ptr(batch), ptr(pos), ptr(self.all_timestamps), ptr(self.event_queue),
              ptr(indices), self.max_num_neighbors, float(self.radius), float(self.delta_t_us), ptr(buf),
              self.min_index, B, Q, H, W, n, K, st)
         edges = buf[:, buf[1] >= 0]

@@ -1,6 +1,6 @@
 """Mirror of `dagr.model.networks.ema.ModelEMA` (reference src/dagr/model/networks/ema.py:6-51).
 EventAD only uses it as a holder: `.ema` = eval-mode deep copy with gradients off
-(utils/model.py:28-39); `update()` is kept for API completeness."""
+(utils/model.py:28-39); `update()` follows ema.py:40-51 operation by operation (pinned by a fixture produced by the reference's class)."""
 import copy
 import math
 
@@ -22,4 +22,5 @@ class ModelEMA:
         src = model.state_dict()
         for k, v in self.ema.state_dict().items():
             if v.dtype.is_floating_point:
-                v.mul_(d).add_(src[k].detach(), alpha=1.0 - d)
+                v *= d                                           # two roundings, as the reference (ema.py:47-51)
+                v += (1.0 - d) * src[k].detach()

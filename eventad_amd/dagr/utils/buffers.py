@@ -16,8 +16,10 @@ def format_data(data, normalizer=None):
         from ..._lib import call, ptr
         n = int(data.pos.shape[0])
         pos, x = torch.empty((n, 3), dtype=torch.float32, device=data.pos.device), torch.empty(data.x.shape, dtype=torch.float32, device=data.pos.device)
-        call("eventad_format_events", ptr(data.pos.contiguous()), ptr(data.t.contiguous()), ptr(data.x.contiguous()), n,
-             ptr(data.width.contiguous()), ptr(data.height.contiguous()), ptr(data.time_window.contiguous()), ptr(pos), ptr(x),
+        # inputs held in names until after the launch: a temporary made by .contiguous() would be freed (and its block
+        # re-used by the next temporary) before the kernel reads it
+        ins = [t.contiguous() for t in (data.pos, data.t, data.x, data.width, data.height, data.time_window)]
+        call("eventad_format_events", ptr(ins[0]), ptr(ins[1]), ptr(ins[2]), n, ptr(ins[3]), ptr(ins[4]), ptr(ins[5]), ptr(pos), ptr(x),
              torch.cuda.current_stream().cuda_stream)
         data.pos, data.x, data.t = pos, x, None
         return data

@@ -137,9 +137,9 @@ class EventADModel(nn.Module):
                                  (0, getattr(data, "bbox0", None), getattr(data, "bbox0_batch", None))):
             if frame not in frames or boxes is None or bb is None or boxes.shape[0] == 0:
                 continue
-            boxes = boxes.contiguous().float()
+            boxes, bb = boxes.contiguous().float(), bb.contiguous().long()
             call("eventad_roi_pool", ptr(out4.x_padded), ptr(out4.pos_padded), ptr(out4.batch_padded), ptr(out4.n_dev),
-                 out4.x_padded.shape[0], ptr(boxes), ptr(bb.contiguous().long()), boxes.shape[0], frame, 2, W, H, B,
+                 out4.x_padded.shape[0], ptr(boxes), ptr(bb), boxes.shape[0], frame, 2, W, H, B,
                  ptr(feats), st)
         self.batch_feature_cache, self.batch_input_hash = feats, self._calls
         return feats

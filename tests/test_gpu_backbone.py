@@ -172,3 +172,48 @@ def test_both_edge_search_kernels_give_the_same_rows():
                      L.csr_src[:e].clone(), L.rowptr[: n + 1].clone(), res["out4"]["x"][: int(res["out4"]["n_dev"].item())].clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_pooled_positions_at_full_density_and_non_power_of_two_width():
+    """pool1 node positions at 1280x720 with 500k events per clip (~220 events per voxel).  The reference averages
+    normalised fp32 positions (in atomic order on its GPU, sequentially in the oracle) and floors (mean + 1e-5) * W;
+    the HIP path averages exact integer pixel sums.  For a width that is not a power of two the two can only differ
+    where the exact value (sum/n + 1e-5 W) lies within float error of an integer -- possible only for voxels with
+    >= 77 members -- and then by exactly one pixel.  Everything else must be equal."""
+    from fractions import Fraction
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    W, H, n, B = 1280, 720, 500000, 2
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True))
+    cfg = dagr_ref.make_config(W, H, B)
+    _, pos, batch, _, _ = dagr_ref.pooling(torch.zeros(n * B, 1), data.pos, data.batch, torch.zeros((2, 0), dtype=torch.long),
+                                           cfg.voxel[0], cfg.cart_max[1], "max", W, H, B)
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
+    res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    torch.cuda.synchronize()
+    assert nb.check_flags() & ~1 == 0
+    L = res["ws"]["levels"][0]
+    n_l = int(L.n_dev.item())
+    assert n_l == pos.shape[0]
+    got = L.npos[:n_l].cpu()
+    assert torch.equal(L.nbatch[:n_l].cpu().long(), batch)
+    assert torch.allclose(got[:, 2], pos[:, 2], atol=1e-5)
+    bad = torch.nonzero((got[:, :2] != pos[:, :2]).any(1)).flatten().tolist()
+    if bad:
+        # exact per-voxel pixel sums from the integer inputs
+        px = torch.round(data.pos[:, 0] * W).long(); py = torch.round(data.pos[:, 1] * H).long()
+        vs = cfg.voxel[0]
+        start, end = torch.Tensor([0, 0, 0, 0]), torch.Tensor([0.9999999, 0.9999999, 0.9999999, B - 1])
+        cl = dagr_ref.grid_cluster(torch.cat([data.pos, data.batch.float().view(-1, 1)], 1), vs, start, end)
+        _, inv = torch.unique(cl, sorted=True, return_inverse=True)
+        for j in bad:
+            m = inv == j
+            cnt = int(m.sum())
+            assert cnt >= 77, cnt
+            for d, (pix, size) in enumerate(((px, W), (py, H))):
+                if got[j, d] != pos[j, d]:
+                    q = Fraction(int(pix[m].sum()), cnt) + Fraction(size, 100000)
+                    assert abs(q - round(q)) < Fraction(1, 1000), (j, d, float(q))
+                    assert abs(round(float(got[j, d]) * size) - round(float(pos[j, d]) * size)) == 1
+    print("pool1 nodes %d, positions off by one pixel at a rounding boundary: %d" % (n_l, len(bad)))

@@ -160,3 +160,74 @@ def test_native_head_large_batch_matches_autograd():
     for k, p in m.named_parameters():
         if k in native:
             assert torch.allclose(native[k], p.grad, atol=5e-5, rtol=5e-4), k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_roi_pool_kernel_matches_reference_golden_features(name, golden_dir):
+    """eventad_roi_pool on the golden cases' out4 nodes == the batch_features the reference's _process_bbox loop
+    produced (models/EventAD.py:382-397, 406-499): boxes with nodes inside (inverse-distance weights), a far box with
+    none (mean of the 5 nearest), a clip without nodes (zero global feature), dropped rows, 30 tracks per clip."""
+    gold = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    kw = gold["kw"]
+    case = make_head_case(**kw)
+    m = _model(kw["seed"])
+    data = _data(case)
+    n = case["out4_x"].shape[0]
+    pad = 7                                                     # padded rows past n_dev must be ignored
+    out4 = SimpleNamespace(
+        x_padded=torch.cat([case["out4_x"], torch.full((pad, 64), 1e9)]).cuda().contiguous(),
+        pos_padded=torch.cat([case["out4_pos"], torch.full((pad, 3), 0.5)]).cuda().contiguous(),
+        batch_padded=torch.cat([case["out4_batch"], torch.zeros(pad, dtype=torch.long)]).int().cuda().contiguous(),
+        n_dev=torch.tensor([n], dtype=torch.int32).cuda())
+    feats = m.roi_features(out4, data, frames=(0, 1)).cpu()
+    want = gold["feats"]
+    assert feats.shape == want.shape
+    assert torch.equal(feats == 0, want == 0)                   # same (clip, frame, track) slots filled
+    assert torch.allclose(feats, want, atol=2e-5, rtol=1e-4), float((feats - want).abs().max())
+
+
+def test_sliding_window_graph_mirror_and_ev_graph_cuda_module():
+    """The reference-compatible graph builder as the reference drives it: `SlidingWindowGraph.forward/reset`
+    (src/dagr/graph/ev_graph.py:45-103) and the pybind-shaped `ev_graph_cuda` module, both over the C ABI, against the
+    CPU restatement -- two batches with a reset between them, then two batches WITHOUT a reset (growing ids)."""
+    import eventad_amd.compat as compat
+    compat.install()
+    import ev_graph_cuda
+    from dagr.graph.ev_graph import SlidingWindowGraph
+    from eventad_amd import synthetic
+    from oracle import graph as G
+    W = H = 48; B = 2; Q = 16; K = 16; r = 2; dt = 4000
+    mine = SlidingWindowGraph(width=W, height=H, batch_size=B, max_num_neighbors=K, max_queue_size=Q, radius=r, delta_t_us=dt)
+    ref = G.SlidingWindowGraphRef(W, H, B, K, Q, r, dt)
+
+    def batch(first, n):
+        d = synthetic.make_batch(W, H, n, B, first_clip=first, with_image=False, t_span_us=20000)
+        pos_i = torch.stack([d.pos[:, 0].int(), d.pos[:, 1].int(), d.t.int()], 1).contiguous()
+        return d.batch.int().contiguous(), pos_i
+
+    for step, (first, n, reset) in enumerate(((0, 3000, True), (2, 2500, True), (4, 2000, False))):
+        b, p = batch(first, n)
+        if reset:
+            mine.reset(); ref.reset()
+        got = mine.forward(b.cuda(), p.cuda(), delete_nodes=False, collect_edges=True)
+        want = ref.forward(b, p)
+        assert torch.equal(got.cpu(), want), step
+        assert torch.equal(mine.event_queue.cpu(), ref.event_queue), step
+    # the raw module functions with the pybind signatures (ev_graph.cu:279-283)
+    b, p = batch(6, 1500)
+    ref.reset()
+    want = ref.forward(b, p)
+    N = len(b)
+    queue = torch.full((B, Q, H, W), -1, dtype=torch.int32, device="cuda")
+    lin = p[:, 0] + W * p[:, 1] + W * H * b
+    s_lin, s_idx = torch.sort(lin, stable=True)
+    uniq, counts = torch.unique_consecutive(s_lin, return_counts=True)
+    idx = torch.arange(N, dtype=torch.int32)
+    q2 = ev_graph_cuda.insert_in_queue_cuda(idx[s_idx].contiguous().cuda(), uniq.int().cuda(), torch.cumsum(counts, 0).int().cuda(), queue)
+    assert q2 is queue and torch.equal(queue.cpu(), ref.event_queue)
+    edges = torch.full((2, K * N), -1, dtype=torch.int64, device="cuda")
+    ev_graph_cuda.fill_edges_cuda(b.cuda(), p.cuda(), p[:, 2].contiguous().cuda(), queue, idx.cuda(), K, float(r), float(dt), edges, 0)
+    e = edges.cpu()
+    assert torch.equal(e[:, e[1] >= 0], want)
+    with pytest.raises(RuntimeError):                          # AT_ASSERTM equivalents (ev_graph.cu:9-12)
+        ev_graph_cuda.fill_edges_cuda(b, p.cuda(), p[:, 2].contiguous().cuda(), queue, idx.cuda(), K, float(r), float(dt), edges, 0)
