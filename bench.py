@@ -75,7 +75,7 @@ def algorithmic_bytes(N, E, B, W, H):
     }
 
 
-def cpu_baseline(raw, sd, head_sd, W, H, B, steps=2, warmup=1):
+def cpu_baseline(raw, sd, head_sd, W, H, B, steps=10, warmup=3):
     """The CPU oracle (oracle/, kind "port") running the same optimisation step on the host cores."""
     from oracle import dagr_ref, head_ref
     try:
@@ -126,10 +126,6 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the frozen backbone of batch k+1 with the head update of batch k")
-    ap.add_argument("--single-graph", action="store_true",
-                    help="capture the pipelined step as ONE two-branch hipGraph instead of two single-branch graphs replayed on two "
-                         "event-coupled streams with the head on a high-priority stream (measured on C2: 7050 vs 7180 clips/s)")
-    ap.add_argument("--pipeline-stages", type=int, default=2, choices=(2, 3))   # measured on C2: 2 stages 1.65 ms, 3 stages 1.83 ms
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,14 +161,11 @@ def main():
         ts.step(data)
     if use_graph:
         try:
-            if pipelined and a.pipeline_stages == 3 and not a.single_graph:
-                ts.capture_triple(data)
-                run = lambda: ts.replay_triple(join=False)
-            elif pipelined and a.pipeline_stages == 2 and not a.single_graph:
-                ts.capture_dual(data)                          # backbone graph || head graph on two streams
-                run = lambda: ts.replay_dual(join=False)   # event-coupled streams; the timed region ends with a device-wide sync
+            if pipelined:
+                ts.capture_dual(data)                          # backbone graph || head graph on two event-coupled streams
+                run = lambda: ts.replay_dual(join=False)       # the timed region ends with a device-wide sync
             else:
-                ts.capture(data, pipelined=(a.pipeline_stages if pipelined else False))
+                ts.capture(data)
                 run = ts.replay
         except Exception as e:                                 # e.g. a collective that cannot be captured: launch eagerly
             print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e), file=sys.stderr)
@@ -216,9 +209,10 @@ def main():
                                                                                   else "precomputed CNN feature maps", B),
                        "global_batch": world * B, "events_per_batch_per_gpu": N, "realised_edges_per_gpu": E,
                        "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
-                       "pipeline": ("none" if not pipelined else ("backbone(k+1) || head update(k), 2 streams in one graph" if a.single_graph else
-                                                                  "backbone(k+1) || head update(k): two graphs on two event-coupled streams") if a.pipeline_stages == 2
-                                    else "backbone front(k+2) || backbone tail+ROI(k+1) || head update(k), 3 streams in one graph"), "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
+                       "pipeline": ("none" if not pipelined else "backbone(k+1) || head update(k): two graphs on two event-coupled streams"),
+                       "input": "device-resident batch, H2D copy excluded; every step runs the full backbone + head update on it",
+                       "skipped_vs_reference": "ROI pooling of the previous-frame boxes (computed by the reference, never read by its forward)",
+                       "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
                        "final_loss": round(float(loss), 4)},
         }
         if nb.timing:

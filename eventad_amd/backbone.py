@@ -40,6 +40,8 @@ class NativeBackbone:
         self.device = torch.device(device)
         self.prefix = prefix
         self._ws_key = None
+        self.keep_superseded_workspaces = False     # set once a hipGraph holds raw pointers into the workspace: a workspace
+        self._retired_ws = []                       # that has to grow is then retired (kept alive) instead of freed
         # edge-search kernel: -1 = thread per event, ELL row in registers (fastest on C2: 130 us); >0 = LDS-staged strips of
         # that many pixels (139 us at 64); 0 = batched prefetch (175 us).  All bit-identical (tools/microbench_ell.py).
         # edge-search kernel (see eventad_build_ell); None = by expected window occupancy: the row scan (1) for sparse
@@ -95,6 +97,8 @@ class NativeBackbone:
         if self._ws_key is not None and self._ws_key[1] == B and N <= self._ws_key[0]:
             return self.ws                                   # event-indexed arrays only need >= N rows: a loader's varying
                                                              # batch sizes re-use the workspace of the largest batch seen
+        if self._ws_key is not None and self.keep_superseded_workspaces:
+            self._retired_ws.append(self.ws)
         g, dev = self.geom, self.device
         P = B * g.H * g.W
         K = g.max_neighbors

@@ -394,7 +394,7 @@ extern "C" int eventad_colsum_group(int n, const int64_t* desc, int R, void* str
 
 // ------------------------------------------------------------------------------------------------
 // Optimiser: clip_grad_norm_(max_norm) + AdamW on flat fp32 buffers (utils/train.py:27-53,141-152).
-//   state[0]=step  [1]=grad norm  [2]=clip coefficient  [3]=1-beta1^t  [4]=1-beta2^t  [5]=non-finite count
+//   state[0]=step  [1]=grad norm  [2]=clip coefficient  [3]=1-beta1^t  [4]=1-beta2^t  [5]=non-finite count  [6]=this update was skipped
 #define NORM_BLOCKS 256
 __global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, int n, float* __restrict__ partial) {
     __shared__ float red[256];
@@ -411,12 +411,20 @@ __global__ void k_opt_prepare(const float* __restrict__ partial, float max_norm,
     float s = 0.f;
     for (int i = 0; i < NORM_BLOCKS; ++i) s += partial[i];
     float norm = sqrtf(s);
+    state[1] = norm;
+    // The reference raises on a non-finite gradient BEFORE optimizer.step() (utils/train.py:144-149), so its weights
+    // stay clean; and a batch without any valid object leaves every p.grad None, which AdamW skips entirely.  Both
+    // cases become a skipped update here: parameters, moments and the step count stay as they are ([6] = 1), the
+    // non-finite case is also counted in [5] for the host's lazy check.
+    const bool finite = isfinite(norm);
+    if (!finite) state[5] += 1.f;
+    if (!finite || norm == 0.f) { state[6] = 1.f; state[2] = 1.f; return; }
+    state[6] = 0.f;
     float step = state[0] + 1.f;
-    state[0] = step; state[1] = norm;
+    state[0] = step;
     float coef = max_norm / (norm + 1e-6f);                 // torch.nn.utils.clip_grad_norm_
     state[2] = coef < 1.f ? coef : 1.f;
     state[3] = (float)(1.0 - pow(beta1, (double)step)); state[4] = (float)(1.0 - pow(beta2, (double)step));
-    if (!isfinite(norm)) state[5] += 1.f;
 }
 
 __global__ void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
@@ -424,6 +432,7 @@ __global__ void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __r
                         const float* __restrict__ state) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (state[6] != 0.f) return;                            // skipped update (see k_opt_prepare)
     float gi = g[i] * state[2];
     g[i] = gi;                                              // grads are left clipped, as clip_grad_norm_ does
     float pi = p[i] * decay;

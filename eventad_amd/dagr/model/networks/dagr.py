@@ -17,12 +17,23 @@ class DAGR(nn.Module):
         self.batch_size = getattr(args, "batch_size", 1)
         self.backbone = Net(args, height=height, width=width)
         self.head = nn.Module()                      # detection head: out of scope (never run by EventAD)
+        # Reference checkpoints carry the detection head's tensors (`head.*`; as `dagr_model.head.*` inside an EventAD
+        # checkpoint, utils/model.py:116).  They are taken out of an incoming state dict before the strict key check --
+        # in a hook, because a parent module's load never calls a child's load_state_dict -- kept as they came, and
+        # written back by state_dict(), so a checkpoint loaded here and saved again still loads strictly in the reference.
+        self._head_passthrough = {}
+        self._register_load_state_dict_pre_hook(self._take_head_keys)
+        self._register_state_dict_hook(DAGR._emit_head_keys)
 
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        kept = {k: v for k, v in state_dict.items() if not k.startswith("head.")}
-        res = super().load_state_dict(kept, strict=strict, **kw)
-        self.backbone._native = None
-        return res
+    def _take_head_keys(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        mine = [k for k in state_dict if k.startswith(prefix + "head.")]
+        if mine:
+            self._head_passthrough = {k[len(prefix):]: state_dict.pop(k) for k in mine}
+
+    @staticmethod
+    def _emit_head_keys(module, state_dict, prefix, local_metadata):
+        for k, v in module._head_passthrough.items():
+            state_dict[prefix + k] = v
 
     def cache_luts(self, width, height, radius):
         """Reference: builds 21 LUTs of up to 14 GB (dagr.py:36-71).  Native: one 49..729-entry LUT

@@ -78,6 +78,12 @@ class Net(nn.Module):
             raise NotImplementedError("native path implements the dagr-s configuration (relu, sum, kernel_size 5, dim 2)")
         if not self.use_image or self.num_scales != 2:
             raise NotImplementedError("EventAD needs use_image=True and num_scales=2 (models/EventAD.py:362)")
+        if getattr(args, "keep_temporal_ordering", False) or getattr(args, "no_events", False):
+            raise NotImplementedError("--keep_temporal_ordering (pooling.py:70-73) and --no_events are not implemented natively")
+        if getattr(args, "img_net", "resnet50") != "resnet50":
+            raise NotImplementedError("the native CNN branch is ResNet-50 (img_net=%r asked)" % (args.img_net,))
+        if str(getattr(args, "pooling_aggr", "max")) != "max":
+            raise NotImplementedError("native pooling implements pooling_aggr=max (pools 1-3; pool 4 is the mean, net.py:95)")
         self.net = HookModule()
         for name, (cin, cout) in zip(LAYER_NAMES, LAYER_DIMS):
             layer = _Holder()
@@ -94,6 +100,12 @@ class Net(nn.Module):
         self.out_channels = [64, 64]
         self.out_channels_cnn = [256, 256]
         self._native = None
+        # any load that reaches this module (its own, DAGR's or EventADModel's) makes the native weight images stale
+        self.register_load_state_dict_post_hook(Net._drop_native)
+
+    @staticmethod
+    def _drop_native(module, incompatible_keys):
+        module._native = None
 
     def prepare(self, device=None):
         """(Re)build the native weight images from the current parameters (called by DAGR.cache_luts)."""

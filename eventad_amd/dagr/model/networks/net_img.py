@@ -61,6 +61,7 @@ class HookModule(nn.Module):
         self.feature_dconv = nn.ModuleList([nn.Conv2d(ci, co, 1) for ci, co in zip(TAPS, feature_channels)])
         self.output_dconv = nn.ModuleList([nn.Conv2d(ci, co, 1) for ci, co in zip(TAPS[3:], output_channels)])
         self.feature_channels = list(feature_channels)
+        self.register_load_state_dict_post_hook(HookModule._drop_native)
 
     def train(self, mode=True):
         self._native = None
@@ -70,9 +71,9 @@ class HookModule(nn.Module):
         self._native = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
-        self._native = None
-        return super().load_state_dict(*a, **k)
+    @staticmethod
+    def _drop_native(module, incompatible_keys):            # runs for nested loads too (a parent's load_state_dict)
+        module._native = None
 
     @torch.no_grad()
     def forward(self, image):

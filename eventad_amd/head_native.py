@@ -13,20 +13,7 @@ import torch
 from ._lib import call, ptr
 
 NT = 32
-# used head parameters in flat-buffer order (fusion_module.attention.* never receives a gradient, EventAD.py:20)
-PARAMS = [
-    ("gru_net_event.gru.weight_ih_l0", (768, 64)), ("gru_net_event.gru.weight_hh_l0", (768, 256)),
-    ("gru_net_event.gru.bias_ih_l0", (768,)), ("gru_net_event.gru.bias_hh_l0", (768,)),
-    ("gru_net_event.gru.weight_ih_l1", (768, 256)), ("gru_net_event.gru.weight_hh_l1", (768, 256)),
-    ("gru_net_event.gru.bias_ih_l1", (768,)), ("gru_net_event.gru.bias_hh_l1", (768,)),
-    ("gru_net_cor.gru.weight_ih_l0", (96, 4)), ("gru_net_cor.gru.weight_hh_l0", (96, 32)),
-    ("gru_net_cor.gru.bias_ih_l0", (96,)), ("gru_net_cor.gru.bias_hh_l0", (96,)),
-    ("fusion_module.event_proj.weight", (256, 256)), ("fusion_module.event_proj.bias", (256,)),
-    ("fusion_module.coord_proj.weight", (256, 32)), ("fusion_module.coord_proj.bias", (256,)),
-    ("fusion_module.fusion.0.weight", (256, 512)), ("fusion_module.fusion.0.bias", (256,)),
-    ("fusion_module.fusion.3.weight", (2, 256)), ("fusion_module.fusion.3.bias", (2,)),
-    ("soft_attention.weight", (256, 1)), ("soft_attention_cor.weight", (32, 1)),
-]
+from .ddp import PARAMS, flat_layout      # used head parameters in flat-buffer order = the all-reduce bucket layout
 
 
 def _rp(t):
@@ -48,12 +35,9 @@ class NativeHead:
         dev = params[PARAMS[0][0]].device
         assert dev.type == "cuda", "the native head needs the model on a GPU (no CPU path)"
         self.dev = dev
-        self.off, off = {}, 0
         for name, shape in PARAMS:
             assert tuple(params[name].shape) == shape, name
-            self.off[name] = off
-            n = params[name].numel()
-            off += (n + 3) // 4 * 4                           # keep every tensor 16-byte aligned
+        self.off, off = flat_layout()                         # every tensor 16-byte aligned
         self.n = off
         self.flat = torch.zeros(off, device=dev)
         self.grads = torch.zeros(off, device=dev)
@@ -72,6 +56,8 @@ class NativeHead:
                                                            # autograd would add the bridge's result onto itself)
             self.P[name], self.G[name] = v, g
         self._B = None
+        self.keep_superseded_workspaces = False               # set once a hipGraph holds pointers into the workspace
+        self._retired_ws = []
 
     def bound(self):
         """True while the model's parameters still alias the flat buffer (a later .to()/.cuda() breaks it)."""
@@ -82,6 +68,8 @@ class NativeHead:
     def _alloc(self, B):
         if self._B == B:
             return
+        if self._B is not None and self.keep_superseded_workspaces:
+            self._retired_ws.append(self.w)                   # a captured graph may still read and write it
         R, dev = B * NT, self.dev
         f = lambda *s: torch.zeros(s, device=dev)
         i = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)

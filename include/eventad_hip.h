@@ -230,7 +230,10 @@ int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const 
 /* up to 8 column sums per launch; desc = HOST array, 4 int64 per problem: [0] A [1] out [2] lda [3] N */
 int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream);
 /* clip_grad_norm_ + AdamW on flat buffers (utils/train.py:27-53,141-152).  state f32[8]:
- * [0] step, [1] grad norm, [2] clip coefficient, [3] 1-beta1^t, [4] 1-beta2^t, [5] non-finite-norm count. */
+ * [0] step, [1] grad norm, [2] clip coefficient, [3] 1-beta1^t, [4] 1-beta2^t, [5] non-finite-norm count, [6] 1 if this
+ * update was skipped.  A non-finite norm (the reference raises before optimizer.step(), utils/train.py:144-149) or an
+ * all-zero gradient (no valid object: the reference's grads are None and AdamW skips them) leaves params, moments and
+ * the step count untouched. */
 int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr, double beta1,
                        double beta2, double eps, double weight_decay, double max_norm, float* partial, float* state,
                        void* stream);

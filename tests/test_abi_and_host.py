@@ -90,3 +90,46 @@ def test_format_data_matches_oracle():
     raw = synthetic.make_batch(64, 48, 500, 2, with_image=True)
     a, b = format_data(raw.clone()), dagr_ref.format_data(raw.clone())
     assert torch.equal(a.pos, b.pos) and torch.equal(a.x, b.x) and torch.equal(a.image, b.image) and a.t is None
+
+
+def test_reference_checkpoints_with_detection_head_keys_round_trip():
+    """The reference saves `model.state_dict()` of EventADModel -- including the YOLOX detection head under
+    `dagr_model.head.*` -- and loads it strictly at the MODEL level (utils/model.py:87,116; utils/base.py:85).  The head's
+    tensors are taken out in a hook (a parent's load never calls DAGR.load_state_dict), kept, and written back."""
+    from types import SimpleNamespace
+    from eventad_amd.config.eventad_config import parse_eventad_args
+    from eventad_amd.dagr.model.networks.dagr import DAGR
+    from eventad_amd.models.EventAD import EventADModel
+    from eventad_amd import weights
+    args = parse_eventad_args([])
+    model = EventADModel(DAGR(args, height=64, width=64))
+    net = model.dagr_model.backbone
+    net._native = "stale"
+    net.net._native = "stale"
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    extra = {"dagr_model.head.stem1.conv.weight": torch.randn(25, 64, 32), "dagr_model.head.cls_pred1.bias": torch.randn(2),
+             "dagr_model.head.cnn_head.stems.0.conv.weight": torch.randn(8, 8, 1, 1)}
+    sd.update(extra)
+    sd["dagr_model.backbone.layer3.conv_block1.conv.weight"] = sd["dagr_model.backbone.layer3.conv_block1.conv.weight"] + 1.0
+    res = model.load_state_dict(sd, strict=True)                       # model level, strict: as the reference does
+    assert not res.missing_keys and not res.unexpected_keys
+    assert net._native is None and net.net._native is None             # native weight images are rebuilt on next use
+    out = model.state_dict()
+    assert set(out) == set(sd)
+    for k, v in extra.items():
+        assert torch.equal(out[k], v)
+    # a DAGR-level strict load of checkpoint['ema'] (utils/model.py:31-32) takes the same route
+    dagr = DAGR(args, height=64, width=64)
+    ema_sd = {k[len("dagr_model."):]: v for k, v in sd.items() if k.startswith("dagr_model.")}
+    res = dagr.load_state_dict(ema_sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys and set(dagr.state_dict()) == set(ema_sd)
+    with pytest.raises(RuntimeError):                                  # anything else unknown is still an error
+        model.load_state_dict(dict(sd, **{"dagr_model.backbone.bogus": torch.zeros(1)}), strict=True)
+
+
+def test_unsupported_network_flags_raise():
+    from eventad_amd.config.eventad_config import parse_eventad_args
+    from eventad_amd.dagr.model.networks.dagr import DAGR
+    for flag in (["--keep_temporal_ordering"], ["--no_events"], ["--img_net", "resnet18"], ["--pooling_aggr", "mean"]):
+        with pytest.raises(NotImplementedError):
+            DAGR(parse_eventad_args(flag), height=64, width=64)

@@ -231,3 +231,30 @@ def test_sliding_window_graph_mirror_and_ev_graph_cuda_module():
     assert torch.equal(e[:, e[1] >= 0], want)
     with pytest.raises(RuntimeError):                          # AT_ASSERTM equivalents (ev_graph.cu:9-12)
         ev_graph_cuda.fill_edges_cuda(b, p.cuda(), p[:, 2].contiguous().cuda(), queue, idx.cuda(), K, float(r), float(dt), edges, 0)
+
+
+def test_optimiser_skips_non_finite_and_all_zero_gradients():
+    """The reference raises on a non-finite gradient before optimizer.step() (utils/train.py:144-149) and AdamW skips
+    parameters whose grad is None (a batch without valid objects): in both cases weights, moments and the step count
+    must stay exactly as they were; the non-finite case is counted for the host's lazy check."""
+    m = _model(12)
+    nh = m.native_head(lr=1e-3, weight_decay=1e-5, grad_clip=1.0)
+    g = torch.Generator().manual_seed(3)
+    nh.grads.copy_(torch.randn(nh.n, generator=g).cuda())
+    nh.optimizer_step()                                          # one ordinary step so the moments are non-zero
+    torch.cuda.synchronize()
+    before = [t.clone() for t in (nh.flat, nh.exp_avg, nh.exp_avg_sq)]
+    assert float(nh.opt_state[0]) == 1.0 and float(nh.opt_state[6]) == 0.0
+    for poison, counted in ((float("nan"), 1), (float("inf"), 2), (None, 2)):
+        nh.grads.zero_()
+        if poison is not None:
+            nh.grads[12345] = poison
+        nh.optimizer_step()
+        torch.cuda.synchronize()
+        for a, b in zip((nh.flat, nh.exp_avg, nh.exp_avg_sq), before):
+            assert torch.equal(a, b)
+        assert float(nh.opt_state[0]) == 1.0 and float(nh.opt_state[6]) == 1.0 and nh.nonfinite_steps() == counted
+    nh.grads.copy_(torch.randn(nh.n, generator=g).cuda())        # and the next ordinary step goes through
+    nh.optimizer_step()
+    torch.cuda.synchronize()
+    assert float(nh.opt_state[0]) == 2.0 and float(nh.opt_state[6]) == 0.0 and not torch.equal(nh.flat, before[0])

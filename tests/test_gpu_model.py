@@ -133,39 +133,82 @@ def test_live_cnn_configurations_match_oracle(W, H, B, n):
 
 
 def test_pipelined_and_graph_steps_equal_sequential_steps():
-    """backbone(k+1) || head(k) on two streams, eagerly and as a replayed hipGraph, must leave exactly the
-    weights that plain sequential steps leave (the backbone is frozen, so the overlap changes nothing)."""
+    """backbone(k+1) || head(k) on two streams, eagerly and as replayed hipGraphs, with a DIFFERENT batch every step,
+    must leave exactly the weights that plain sequential steps over the same batches leave: the head has to see the
+    boxes and labels of the batch that produced its features, whatever the launch form."""
+    from eventad_amd import synthetic
     from eventad_amd.train_step import TrainStep
     W = H = 64; B = 3; n = 3000
     results = []
-    for mode in ("sequential", "pipelined", "graph", "graph3", "dual", "dual_nojoin", "triple"):
+    for mode in ("sequential", "pipelined", "graph", "dual", "dual_nojoin"):
         args, model, sd, head_sd, raw, data = _build(W, H, B, n)
+        from dagr.utils.buffers import format_data
+        batches = [data] + [format_data(synthetic.make_batch(W, H, n, B, first_clip=3 * k, with_image=False,
+                                                              precomputed_feats=True).to("cuda:0")) for k in (1, 2, 3)]
+        assert not torch.equal(batches[0].bbox, batches[1].bbox) and batches[0].bbox.shape == batches[1].bbox.shape
         model.eval()
         ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
+        losses = []
         if mode == "sequential":
-            for _ in range(4):
-                loss, norm = ts.step(data)
+            for b in batches:
+                losses.append(ts.step(b)[0].clone())
         elif mode == "pipelined":
-            ts.prime(data)
-            for _ in range(4):
-                loss, norm = ts.pipelined_step(data)
-        elif mode == "triple":                               # three graphs on three streams: prime 1 + warm-up 1 ...
-            ts.capture_triple(data, warmup=1)
-            for _ in range(3):                               # ... + 3 replays = 4 updates
-                loss, norm = ts.replay_triple()
-        elif mode in ("dual", "dual_nojoin"):
-            ts.capture_dual(data, warmup=1)                  # two single-branch graphs on two streams
-            for _ in range(3):
-                loss, norm = ts.replay_dual(join=(mode == "dual"))
+            ts.prime(batches[0])
+            for k, b in enumerate(batches):
+                losses.append(ts.pipelined_step(b, None, batches[min(k + 1, 3)])[0].clone())
+        elif mode == "graph":
+            buf = batches[0].clone()
+            ts.capture(buf, warmup=2)                        # capturing leaves the weights untouched
+            for b in batches:
+                TrainStep.load_into(buf, b)
+                losses.append(ts.replay()[0].clone())
         else:
-            ts.capture(data, pipelined=(3 if mode == "graph3" else True), warmup=1)   # warm-up 1 + capture 0 ...
-            for _ in range(3):                               # ... + 3 replays = 4 updates
-                loss, norm = ts.replay()
+            join = mode == "dual"
+            ts.capture_dual(batches[0], warmup=2)
+            for b in batches[1:]:
+                loss, norm = ts.replay_dual(b, join=join)
+                if join:
+                    losses.append(loss.clone())
+            loss, norm = ts.flush()
+            losses.append(loss.clone())
         torch.cuda.synchronize()
         ts.check()
-        results.append(({k: v.clone() for k, v in ts.nh.P.items()}, float(loss), float(norm)))
+        results.append(({k: v.clone() for k, v in ts.nh.P.items()}, [float(l) for l in losses], float(ts.nh.opt_state[0])))
     ref = results[0]
+    assert len(set(ref[1])) == 4                              # four different batches, four different losses
     for got in results[1:]:
-        assert abs(got[1] - ref[1]) < 1e-5 * max(1.0, abs(ref[1])) and abs(got[2] - ref[2]) < 1e-5 * max(1.0, ref[2])
+        assert got[2] == ref[2] == 4.0                        # optimiser step count
+        assert got[1] == ref[1][-len(got[1]):]                # every loss the mode reported, bit for bit
         for k in ref[0]:
             assert torch.equal(got[0][k], ref[0][k]), k       # the whole path is free of float atomics: bitwise reproducible
+
+
+def test_earlier_capture_survives_a_workspace_reallocation():
+    """A captured graph holds raw pointers into the native workspaces.  Capturing a larger batch afterwards makes the
+    event-level workspace grow; the superseded one must stay alive so that the first graph still replays correctly."""
+    from dagr.utils.buffers import format_data
+    from eventad_amd import synthetic
+    from eventad_amd.train_step import TrainStep
+    W = H = 64; B = 2
+    args, model, sd, head_sd, raw, small = _build(W, H, B, 2000)
+    big = format_data(synthetic.make_batch(W, H, 6000, B, with_image=False, precomputed_feats=True).to("cuda:0"))
+    model.eval()
+    ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
+    g1 = ts.capture(small, warmup=1)
+    loss1, norm1 = ts._g_loss, ts._g_norm
+    nb = model.dagr_model.backbone._native
+    ws_before = nb.ws
+    ts.capture(big, warmup=1)                                 # N grows: new workspace
+    assert nb.ws is not ws_before and any(w is ws_before for w in nb._retired_ws)
+    junk = [torch.full((1 << 22,), 7.0, device="cuda") for _ in range(8)]   # would land in freed blocks, were they freed
+    snap = ts.snapshot()
+    g1.replay()
+    torch.cuda.synchronize()
+    got = (float(loss1), float(norm1), {k: v.clone() for k, v in ts.nh.P.items()})
+    ts.restore(snap)
+    loss, norm = ts.step(small)
+    torch.cuda.synchronize()
+    assert (float(loss), float(norm)) == got[:2]
+    for k, v in ts.nh.P.items():
+        assert torch.equal(v, got[2][k]), k
+    del junk
