@@ -57,24 +57,24 @@ class NativeBackbone:
         g, dev, pre = self.geom, self.device, self.prefix
         sd = {k: v.detach().float().cpu() for k, v in sd.items() if k.startswith(pre)}
         w = {}
-        # event-level Layer (conv_block1): LUT per spiral step, Cin padded 19 -> 20
+        # event-level Layer (conv_block1): LUT per spiral step, Cin padded 19 -> 20.  Every node's first ELL slot is its
+        # self edge, whose LUT cell is spiral step 0: W_root x_i + LUT[0] x_i is one mat-vec with LUT[0] + W_root, appended
+        # as LUT row `steps` (other edges from the same pixel keep LUT[0]).  The eval-mode BatchNorm that follows each conv
+        # is an affine map per output channel: its scale is multiplied into the weights' output columns here, its shift is
+        # added in the kernel's epilogue (conv 2: conv shift + skip shift), so a node's output is one accumulation.
         p1, p2 = pre + "conv_block1.conv_block1.", pre + "conv_block1.conv_block2."
-        w["lut1"] = spline.lut_by_spiral_step(sd[p1 + "conv.weight"], g, 20)
-        w["root1"] = spline.pad_rows(sd[p1 + "conv.lin.weight"].t().contiguous(), 20)
-        w["bn1"] = spline.fold_bn(sd, p1 + "norm.module.")
-        w["lut2"] = spline.lut_by_spiral_step(sd[p2 + "conv.weight"], g, 16)
-        w["root2"] = sd[p2 + "conv.lin.weight"].t().contiguous()
-        # Every node's first ELL slot is its self edge, whose LUT cell is spiral step 0: W_root x_i + LUT[0] x_i is one
-        # mat-vec with LUT[0] + W_root, appended as LUT row `steps` (other edges from the same pixel keep LUT[0]).  The
-        # layer-1 convs are LDS-bandwidth bound (one Cin x 16 matrix read per edge), so this removes ~10 % of their LDS
-        # traffic; the sum differs from the two-term form by fp32 rounding only.
-        self.fold_root = os.environ.get("EVENTAD_FOLD_ROOT", "1") == "1"
-        if self.fold_root:
-            w["lut1"] = torch.cat([w["lut1"], (w["lut1"][0] + w["root1"]).unsqueeze(0)]).contiguous()
-            w["lut2"] = torch.cat([w["lut2"], (w["lut2"][0] + w["root2"]).unsqueeze(0)]).contiguous()
-        w["bn2"] = spline.fold_bn(sd, p2 + "norm.module.")
-        w["wskip"] = spline.pad_rows(sd[p2 + "lin.mlp.weight"].t().contiguous(), 20)
-        w["bns"] = spline.fold_bn(sd, p2 + "norm_skip.module.")
+        sc1, sh1 = spline.fold_bn(sd, p1 + "norm.module.")
+        sc2, sh2 = spline.fold_bn(sd, p2 + "norm.module.")
+        scs, shs = spline.fold_bn(sd, p2 + "norm_skip.module.")
+        lut1 = spline.lut_by_spiral_step(sd[p1 + "conv.weight"], g, 20)
+        root1 = spline.pad_rows(sd[p1 + "conv.lin.weight"].t().contiguous(), 20)
+        lut2 = spline.lut_by_spiral_step(sd[p2 + "conv.weight"], g, 16)
+        root2 = sd[p2 + "conv.lin.weight"].t().contiguous()
+        w["lut1"] = spline.quad_row_order(torch.cat([lut1, (lut1[0] + root1).unsqueeze(0), torch.zeros(1, 20, 16)]) * sc1.view(1, 1, 16))
+        w["lut2"] = spline.quad_row_order(torch.cat([lut2, (lut2[0] + root2).unsqueeze(0), torch.zeros(1, 16, 16)]) * sc2.view(1, 1, 16))
+        w["shift1"] = sh1.contiguous()
+        w["wskip"] = spline.quad_row_order(spline.pad_rows(sd[p2 + "lin.mlp.weight"].t().contiguous(), 20) * scs.view(1, 16))
+        w["shift2"] = (sh2 + shs).contiguous()
         # pooled Layers: X.[W_0..W_24 | root | skip]  and  Y1.[W_0..W_24 | root]
         self.tail_w = []
         for name, (cin, cout) in list(zip(LAYER_NAMES, LAYER_DIMS))[1:]:
@@ -105,12 +105,12 @@ class NativeBackbone:
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         # zero-initialised scratch of the event-level stage, back to back so eventad_sort_events clears it with ONE
-        # memset: [counters(4) | pixel histogram(P+1) | pool1 neighbour bitmap(3*S0)]
+        # fill: [counters(4) | pixel histogram(P+1) | pool1 neighbour bitmap(3*S0) | work counters of the two convs (2 x 256)]
         S0_ = g.grid[0][0] * g.grid[0][1] * (B + 1)
-        front_arena = torch.zeros(4 + P + 1 + 3 * S0_, dtype=torch.int32, device=dev)
+        front_arena = torch.zeros(4 + P + 1 + 3 * S0_ + 512 + 32, dtype=torch.int32, device=dev)
         ws = dict(
             front_arena=front_arena, counters=front_arena[:4], pix_count=front_arena[4:4 + P + 1],
-            bitmap0=front_arena[4 + P + 1:].view(S0_, 3),
+            bitmap0=front_arena[4 + P + 1:4 + P + 1 + 3 * S0_].view(S0_, 3), l1_work=front_arena[(4 + P + 1 + 3 * S0_ + 31) // 32 * 32:][:512],     # 128-byte aligned
             key=i32(N), tq=i32(N), bev=i32(N), pix_start=i32(P + 1),
             scan_tmp=i32(2 * (max(P, 1 << 16) // 2048 + 4)), sid_tmp=i32(N), sid=i32(N),
             key_s=i32(N), ts_s=i32(N), ev2=i32(N, 2), posn_s=f32(N, 3), x0s=f32(N, 20),
@@ -249,7 +249,7 @@ class NativeBackbone:
              ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["counters"]),
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
-             ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), 3 * L0_.S, st)     # also clears counters, histogram, pool1 bitmap
+             ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), 3 * L0_.S + 512 + 32, st)     # also clears counters, histogram, pool1 bitmap, work counters
         sw = self.ell_variant
         if sw is None:
             window = (2 * g.radius_px + 1) ** 2 * N / max(B * g.W * g.H, 1)         # mean events per search window
@@ -260,10 +260,9 @@ class NativeBackbone:
              ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],
              ptr(ws["levels"][0].bitmap) if self.fused_mark else None, sw, 1, st)
         self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
-             None if self.fold_root else ptr(w["root1"]), ptr(w["bn1"][0]), ptr(w["bn1"][1]), ptr(ws["y1"]), N, g.steps, K, st)
+             ptr(w["shift1"]), ptr(ws["y1"]), ptr(ws["l1_work"][:256]), N, g.steps, K, st)
         self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
-             ptr(w["lut2"]), None if self.fold_root else ptr(w["root2"]), ptr(w["bn2"][0]), ptr(w["bn2"][1]), ptr(w["wskip"]), ptr(w["bns"][0]),
-             ptr(w["bns"][1]), ptr(ws["y2"]), N, g.steps, K, st)
+             ptr(w["lut2"]), ptr(w["wskip"]), ptr(w["shift2"]), ptr(ws["y2"]), ptr(ws["l1_work"][256:]), N, g.steps, K, st)
         L = ws["levels"][0]
         fmap = maps[1]
         # wave-per-voxel segmented max over the pixel CSR (no atomics, no table memsets)

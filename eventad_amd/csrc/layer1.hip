@@ -6,125 +6,239 @@
 //     y2    = ReLU( BN(out2) + BN_skip(W_skip x_i) )                                            (conv 2)
 // The reference gathers LUT[dx,dy] into an [E,Cin,Cout] temporary (36.6 GB in its own comment,
 // spline_conv.py:43-44) and scatter-adds.  Here every destination owns <=16 contiguous ELL slots
-// (graph.hip), the LUT (one Cin x 16 matrix per spiral step, 49 steps at r=3) lives in LDS, and
-// 4 lanes per destination each keep 4 output channels in registers: no atomics, no temporary.
+// (graph.hip), the LUT (one Cin x 16 matrix per spiral step, 49 steps at r=3) lives in LDS, and the 4 lanes of a
+// destination split the INPUT channels: no atomics, no temporary.
+//
+// Weights arrive pre-multiplied by the folded eval-mode BatchNorm scale of their output column (host side:
+// eventad_amd/backbone.py), the shifts pre-summed; LUT row `steps` is the matrix of the self edge that opens every ELL
+// row (LUT[0] + W_root), row `steps + 1` is all zeros (what slots past a row's degree multiply by).  So a node's output is ONE accumulation over its edges (+ the skip product) + shift, ReLU.
+// The rows of every weight matrix come in the order [i][j] = i-th channel of lane j (row i*4 + j holds channel 4j+i for
+// i < 4 and channel 16+j for i = 4), see eventad_amd/spline.py::quad_row_order.
+//
+// Mapping (64-lane waves, 16 destinations per pass, no workgroup barrier after the LUT is staged):
+//  * a wave takes groups of 64 consecutive destinations from a per-XCD work counter (dynamic: groups differ 4x in edge
+//    count), ranks the 64 by degree with ballots, and runs 4 passes of 16 destinations of (nearly) equal degree -- a wave
+//    pays for the longest row of a pass;
+//  * lane j of a destination's quad owns input channels {4j..4j+3} (+ channel 16+j when Cin = 20): a neighbour row
+//    costs one 16-byte (+ one 4-byte) load per lane, each byte of the row fetched once per quad, and only 4-5 registers;
+//    the lane keeps partial sums for all 16 outputs, reduced over the quad once per NODE with DPP adds;
+//  * lane j also holds ELL slots 4j..4j+3 of the row (one int4 + one uint2); slot e reaches the quad by a DPP quad
+//    broadcast (the row is rotated one lane per block of 4 slots, so every lane/component choice is static);
+//  * with the [i][j][16] row order the quad reads 64 consecutive floats of the LDS copy of a LUT matrix;
+//    quad a of a 16-lane group reads its four 16-byte chunks in the order (s + a) & 3, which makes the 16 lanes of a
+//    ds_read_b128 pass hit 16 different bank groups whatever their cells are (cell stride = Cin*16 floats = 0 mod 64);
+//  * neighbour rows are prefetched 4 slots ahead (across pass boundaries), the next pass's ELL row and the next group's id
+//    one step ahead.
 // Messages are added in ELL slot order (self edge, then spiral order) = the reference's edge order.
 #include "common.h"
 
-template <int CINP>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[CINP]) {
-#pragma unroll
-    for (int q = 0; q < CINP / 4; ++q) {
-        float4 v = ((const float4*)p)[q];
-        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-    }
-}
-
-template <int CINP>
-__device__ __forceinline__ float4 matvec4(const float (&x)[CINP], const float* __restrict__ w /* [CINP][16] at lane offset */) {
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < CINP; ++k) {
-        float4 wv = *(const float4*)(w + k * 16);
-        m.x = fmaf(x[k], wv.x, m.x); m.y = fmaf(x[k], wv.y, m.y);
-        m.z = fmaf(x[k], wv.z, m.z); m.w = fmaf(x[k], wv.w, m.w);
-        // keep at most 4 LDS reads in flight: unbounded hoisting of the 20 ds_read_b128 costs 80 VGPRs and spills
-        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    return m;
-}
-
-// LUT row stride in LDS: CINP*16 floats + 16 pad so consecutive steps start 16 banks apart
-// (ds_read_b128 banks are (addr/4)%64; an unpadded CINP*16 stride is a multiple of 64 for CINP=20,16).
 #define L1_THREADS 512          // 8 waves share one LDS copy of the LUT: 2 workgroups/CU = 16 waves/CU
+#define L1_GROUP 64             // destinations per wave and work item (4 passes of 16)
+#define L1_MAX_WG 512
+
+// Per-lane addresses are formed as a 32-bit byte offset from a wave-uniform base pointer (arrays here are < 4 GiB), so
+// the loads take the scalar-base + 32-bit-offset form instead of keeping a 64-bit address per lane in VGPRs.
+template <typename T> __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) {
+    return *(const T*)((const char*)base + byte_off);
+}
+template <int CINP>
+__device__ __forceinline__ void l1_load_row(const float* __restrict__ xin, int src, int j, float4& v, float& e) {
+    const unsigned o = (unsigned)src * (CINP * 4u) + 16u * (unsigned)j;
+    v = ld_off<float4>(xin, o);
+    e = 0.f;
+    if (CINP == 20) e = ld_off<float>(xin, (unsigned)src * 80u + 64u + 4u * (unsigned)j);
+}
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
+// acc[s] += x * W[chunk (s+a)&3] for the KL channels of this lane; wl = row of this lane's channel 0 (rows are stored
+// [i][j], 16 floats each, so channel i is 64 floats further)
+template <int KL>
+__device__ __forceinline__ void l1_fma(float4 (&acc)[4], const float4& xv, float xe, const float* __restrict__ wl,
+                                       const int (&rot)[4]) {
+    const float xs[5] = {xv.x, xv.y, xv.z, xv.w, xe};
+#pragma unroll
+    for (int i = 0; i < KL; ++i) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 w = *(const float4*)(wl + i * 64 + rot[s]);
+            acc[s].x = fmaf(xs[i], w.x, acc[s].x); acc[s].y = fmaf(xs[i], w.y, acc[s].y);
+            acc[s].z = fmaf(xs[i], w.z, acc[s].z); acc[s].w = fmaf(xs[i], w.w, acc[s].w);
+        }
+        // at most two channels' weights (8 x ds_read_b128 = 32 registers) in flight: unbounded hoisting of the 20 reads of an
+        // edge -- and of the next edge's -- runs the kernel out of registers, and a spill's scratch traffic shares vmcnt
+        // with the prefetched rows
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int K> __device__ __forceinline__ int quad_bcast(int v) {      // value of lane K of the quad, in all four lanes
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int quad_rotate(int v) {                       // lane j takes the value of lane (j + 1) & 3
+    return __builtin_amdgcn_update_dpp(0, v, 0x39, 0xf, 0xf, true);       // quad_perm [1,2,3,0]
+}
+template <int S> __device__ __forceinline__ int comp4(const int4& v) { return S == 0 ? v.x : S == 1 ? v.y : S == 2 ? v.z : v.w; }
+
+// One ELL slot (slot 4b + S of the current row; the quad keeps the current block's slots in lane 0 and the next block's in
+// lane 1 by rotating the row one lane per block): consume ring buffer S, refill it with the row that will be consumed 4
+// slots later -- slot 4(b+1) + S of this row, or, in the row's last block, slot S of the NEXT pass's row, so the first
+// rows of the next pass are in flight while this pass reduces and stores.
+// Branch-free on purpose: a load inside a divergent branch lands in a temporary that the compiler can only copy into
+// the ring buffer after waiting for ALL outstanding loads, which serialises the prefetch.  Slots past the row's degree
+// multiply a cached row (the destination's own) by the all-zero matrix LUT[steps + 1] instead.
+template <int CINP, int KL, int S>
+__device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float (&xe)[4], const int4& sv, const uint2& cv,
+                                        const int4& sv2, int b, bool last, bool half, int d, int d2, int j, int safe, int safe2,
+                                        const float* __restrict__ xin, const float* __restrict__ wbase, const int (&rot)[4], int steps) {
+    constexpr int LS = CINP * 16;
+    const int e = 4 * b + S;
+    const int pair = quad_bcast<0>((int)(S & 2 ? cv.y : cv.x));
+    int cell = (S & 1) ? (int)((unsigned)pair >> 16) : (pair & 0xffff);
+    if (S == 0) cell = b == 0 ? steps : cell;                            // the self edge reads the folded root matrix
+    cell = e < d ? cell : steps + 1;
+    int nsrc = quad_bcast<1>(comp4<S>(sv));
+    nsrc = e + 4 < d ? nsrc : safe;
+    int nnext = quad_bcast<0>(comp4<S>(sv2));
+    nnext = S < d2 ? nnext : safe2;
+    // `half` (uniform): the row's last block holds at most two live slots -- slots 2 and 3 only refill their buffers
+    if (S < 2 || !half) l1_fma<KL>(acc, xv[S], xe[S], wbase + (size_t)cell * LS, rot);
+    // the refill comes after the products that read the buffer, so the old row needs no copy
+    l1_load_row<CINP>(xin, last ? nnext : nsrc, j, xv[S], xe[S]);
+}
+
 template <int CINP, bool SKIP, bool LUT_IN_LDS>
 __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
                                                  const uint16_t* __restrict__ ell_step, const int* __restrict__ deg,
-                                                 const float* __restrict__ lut, const float* __restrict__ root,
-                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                 const float* __restrict__ lut, const float* __restrict__ shift,
                                                  const float* __restrict__ xskip, const float* __restrict__ wskip,
-                                                 const float* __restrict__ sscale, const float* __restrict__ sshift,
-                                                 float* __restrict__ out, int N, int steps, int max_nb) {
+                                                 float* __restrict__ out, unsigned* __restrict__ work, int N, int steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LS = CINP * 16 + 16;
-    float* s_root = smem;                                 // [CINP][16]
-    float* s_skip = s_root + CINP * 16;                   // [20][16] (SKIP only)
-    float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [steps][LS]
-    if (root) for (int t = threadIdx.x; t < CINP * 16; t += L1_THREADS) s_root[t] = root[t];
-    if (SKIP) for (int t = threadIdx.x; t < 20 * 16; t += L1_THREADS) s_skip[t] = wskip[t];
-    if (LUT_IN_LDS)
-        for (int t = threadIdx.x; t < (steps + (root ? 0 : 1)) * CINP * 16; t += L1_THREADS) s_lut[(t / (CINP * 16)) * LS + t % (CINP * 16)] = lut[t];
-    __syncthreads();
-
-    const int l4 = (threadIdx.x & 3) * 4;
-    const int node = blockIdx.x * (L1_THREADS / 4) + (threadIdx.x >> 2);
-    if (node >= N) return;
-    const int d = deg[node];
-    // ELL row consumed in quads (int4 of sources + 4 packed cells), the next quad fetched one quad ahead, so the
-    // neighbour gathers never wait on an index load; while one neighbour row is multiplied the next one is
-    // already in flight in the other register buffer (two buffers, alternating: no copies).
-    const int4* sp = (const int4*)(ell_src + (size_t)node * 16);
-    const uint2* cp = (const uint2*)(ell_step + (size_t)node * 16);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float xa[CINP], xb[CINP];
-    load_row<CINP>(xin + (size_t)node * CINP, xa);         // slot 0 is the self edge: src[0] == node
-    auto edge = [&](const float (&xv)[CINP], int cell) {
-        float4 m = LUT_IN_LDS ? matvec4<CINP>(xv, s_lut + cell * LS + l4)
-                              : matvec4<CINP>(xv, lut + (size_t)cell * CINP * 16 + l4);
-        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
-    };
-    int4 sv = sp[0]; uint2 cv = cp[0];
+    constexpr int KL = CINP == 20 ? 5 : 4;                // input channels per lane
+    constexpr int LS = CINP * 16;                         // floats per LUT matrix
+    static_assert(CINP == 20 || CINP == 16, "lane/channel map is written for 20 or 16 input channels");
+    float* s_skip = smem;                                 // [5][4][16] (SKIP only)
+    float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [steps+2][KL][4][16]
+    const int tid = threadIdx.x;
+    // ---- once per workgroup: LUT and skip weights (already in the [i][j][16] row order) into LDS, 16 bytes per lane and trip
+    if (LUT_IN_LDS) {
+        const float4* g4 = (const float4*)lut;
+        float4* s4 = (float4*)s_lut;
+        const int n4 = (steps + 2) * LS / 4;
+        for (int t = tid; t < n4; t += L1_THREADS) s4[t] = g4[t];
+    }
+    if (SKIP) { if (tid < 80) ((float4*)s_skip)[tid] = ((const float4*)wskip)[tid]; }
+    __syncthreads();                                      // the only workgroup barrier: from here on every wave is on its own
+    const int lane = tid & 63, j = lane & 3, q = lane >> 2, a = q & 3;
+    int rot[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e0 = 4 * q;
-        if (e0 < d) {
-            int4 svn = sv; uint2 cvn = cv;
-            if (q < 3 && e0 + 4 < d) { svn = sp[q + 1]; cvn = cp[q + 1]; }
-            if (e0 + 1 < d) load_row<CINP>(xin + (size_t)sv.y * CINP, xb);
-            edge(xa, (q == 0 && !root) ? steps : (int)(cv.x & 0xffff));   // folded root: the self edge reads row `steps`
-            if (e0 + 1 < d) {
-                if (e0 + 2 < d) load_row<CINP>(xin + (size_t)sv.z * CINP, xa);
-                edge(xb, cv.x >> 16);
-                if (e0 + 2 < d) {
-                    if (e0 + 3 < d) load_row<CINP>(xin + (size_t)sv.w * CINP, xb);
-                    edge(xa, cv.y & 0xffff);
-                    if (e0 + 3 < d) {
-                        if (q < 3 && e0 + 4 < d) load_row<CINP>(xin + (size_t)svn.x * CINP, xa);
-                        edge(xb, cv.y >> 16);
-                    }
-                }
-            }
-            sv = svn; cv = cvn;
+    for (int s = 0; s < 4; ++s) rot[s] = ((s + a) & 3) * 4;
+    const float4 sh = *(const float4*)(shift + 4 * j);
+    const float* wbase = (LUT_IN_LDS ? (const float*)s_lut : lut) + j * 16;
+    // Work items: groups of 64 consecutive destinations, handed out by one counter per XCD (blockIdx & 7: workgroups are dealt
+    // round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so the
+    // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
+    const int xcd = blockIdx.x & 7;
+    const int ngroups = (N + L1_GROUP - 1) / L1_GROUP, g8 = (ngroups + 7) >> 3;
+    const int gbeg = xcd * g8, gend = min(gbeg + g8, ngroups);
+    unsigned* ctr = work + 32 * xcd;                      // one 128-byte line per XCD: counters sharing a line serialise like one word
+    auto fetch = [&]() {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1u);
+        return gbeg + (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int g = fetch();
+    while (g < gend) {
+        const int gnext = fetch();                        // its round trip overlaps this group's work
+        const int n0 = g * L1_GROUP;
+        // rank the 64 destinations by degree (descending; ties by lane) with 17 ballots, then invert the ranking
+        const int d_l = n0 + lane < N ? min(ld_off<int>(deg, 4u * (unsigned)(n0 + lane)), 16) : 0;
+        int rank = 0, base = 0;
+#pragma unroll
+        for (int v = 16; v >= 0; --v) {
+            const unsigned long long m = __ballot(d_l == v);
+            if (d_l == v) rank = base + __popcll(m & lt_mask);
+            base += __popcll(m);
         }
+        const int perm = __builtin_amdgcn_ds_permute(rank << 2, lane);      // lane r <- the lane whose rank is r
+        const int dperm = __builtin_amdgcn_ds_permute(rank << 2, d_l);
+        int nl = __shfl(perm, q, 64), d = __shfl(dperm, q, 64);
+        int safe = min(n0 + nl, N - 1);                   // a row that exists: lanes past the end / past their degree load it
+        int4 sv = ld_off<int4>(ell_src, (unsigned)safe * 64u + 16u * (unsigned)j);
+        uint2 cv = ld_off<uint2>(ell_step, (unsigned)safe * 32u + 8u * (unsigned)j);
+        float4 xv[4]; float xe[4];
+        {
+            const int s0 = quad_bcast<0>(sv.x), s1 = quad_bcast<0>(sv.y), s2 = quad_bcast<0>(sv.z), s3 = quad_bcast<0>(sv.w);
+            const int first[4] = {s0, s1, s2, s3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d ? first[u] : safe, j, xv[u], xe[u]);
+        }
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+            const int dmax = __builtin_amdgcn_readfirstlane(d);            // quad 0 of the pass has the longest row
+            if (dmax == 0) break;
+            const int node = n0 + nl;
+            // the next pass's row (ELL slots + degree) is fetched now
+            const int r2 = 16 * (p < 3 ? p + 1 : p) + q;
+            const int nl2 = __shfl(perm, r2, 64), d2 = p < 3 ? __shfl(dperm, r2, 64) : 0;
+            const int safe2 = min(n0 + nl2, N - 1);
+            const int4 sv2 = ld_off<int4>(ell_src, (unsigned)safe2 * 64u + 16u * (unsigned)j);
+            const uint2 cv2 = ld_off<uint2>(ell_step, (unsigned)safe2 * 32u + 8u * (unsigned)j);
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f); float ke = 0.f;
+            if (SKIP) l1_load_row<20>(xskip, safe, j, kv, ke);
+            float4 acc[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+            for (int b = 0; 4 * b < dmax; ++b) {
+                const bool last = 4 * (b + 1) >= dmax, half = dmax - 4 * b <= 2;
+#define L1_E(S) l1_edge<CINP, KL, S>(acc, xv, xe, sv, cv, sv2, b, last, half, d, d2, j, safe, safe2, xin, wbase, rot, steps)
+                L1_E(0); L1_E(1); L1_E(2); L1_E(3);
+#undef L1_E
+                sv.x = quad_rotate(sv.x); sv.y = quad_rotate(sv.y); sv.z = quad_rotate(sv.z); sv.w = quad_rotate(sv.w);
+                cv.x = (unsigned)quad_rotate((int)cv.x); cv.y = (unsigned)quad_rotate((int)cv.y);
+            }
+            if (SKIP) {                                   // skip branch on the layer's input row (conv.py:50)
+                int sk = j * 16;
+                asm volatile("" : "+v"(sk));              // opaque: or the 20 loop-invariant weight reads are hoisted out of
+                l1_fma<5>(acc, kv, ke, s_skip + sk, rot); // every loop and held in 80 registers for the kernel's lifetime
+            }
+            // reduce the partial sums over the quad; lane j keeps output chunk j, which sits in accumulator (j - a) & 3
+            float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int mine = (j - a) & 3;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 t = make_float4(quad_sum(acc[s].x), quad_sum(acc[s].y), quad_sum(acc[s].z), quad_sum(acc[s].w));
+                if (s == mine) r4 = t;
+            }
+            if (d > 0) {
+                float4 y = make_float4(fmaxf(r4.x + sh.x, 0.f), fmaxf(r4.y + sh.y, 0.f), fmaxf(r4.z + sh.z, 0.f), fmaxf(r4.w + sh.w, 0.f));
+                *(float4*)((char*)out + ((unsigned)node * 64u + 16u * (unsigned)j)) = y;
+            }
+            safe = safe2; nl = nl2; d = d2; sv = sv2; cv = cv2;
+        }
+        g = gnext;
     }
-    if (root) {                                              // root weight (spline_conv.py:72-73); NULL = the caller appended
-        float x[CINP];                                       // lut[steps] = lut[0] + root, the matrix of the self edge
-        load_row<CINP>(xin + (size_t)node * CINP, x);
-        float4 m = matvec4<CINP>(x, s_root + l4);
-        acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
-    }
-    float4 sc = *(const float4*)(scale + l4), sh = *(const float4*)(shift + l4);
-    float4 y = make_float4(fmaf(acc.x, sc.x, sh.x), fmaf(acc.y, sc.y, sh.y), fmaf(acc.z, sc.z, sh.z), fmaf(acc.w, sc.w, sh.w));
-    if (SKIP) {
-        float xs[20];
-        load_row<20>(xskip + (size_t)node * 20, xs);
-        float4 k = matvec4<20>(xs, s_skip + l4);
-        float4 ks = *(const float4*)(sscale + l4), kh = *(const float4*)(sshift + l4);
-        y.x += fmaf(k.x, ks.x, kh.x); y.y += fmaf(k.y, ks.y, kh.y); y.z += fmaf(k.z, ks.z, kh.z); y.w += fmaf(k.w, ks.w, kh.w);
-    }
-    y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
-    *(float4*)(out + (size_t)node * 16 + l4) = y;
 }
 
 template <int CINP, bool SKIP>
 static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_step, const int* deg, const float* lut,
-                     const float* root, const float* scale, const float* shift, const float* xskip, const float* wskip,
-                     const float* sscale, const float* sshift, float* out, int N, int steps, int max_nb, hipStream_t st) {
-    constexpr int LS = CINP * 16 + 16;
-    size_t fixed = sizeof(float) * (CINP * 16 + (SKIP ? 320 : 0));
-    size_t with_lut = fixed + sizeof(float) * (size_t)(steps + (root ? 0 : 1)) * LS;
-    if (max_nb != 16) return EVAD_ERR_ARG;              // the ELL row is read as 4 x int4 + 2 x uint4
-    dim3 grid(evad_blocks(N, L1_THREADS / 4)), block(L1_THREADS);
+                     const float* shift, const float* xskip, const float* wskip, float* out, unsigned* work, int N, int steps,
+                     int max_nb, hipStream_t st) {
+    constexpr int LS = CINP * 16;
+    if (max_nb != 16) return EVAD_ERR_ARG;              // an ELL row is read as 4 x int4 + 4 x uint2
+    size_t fixed = sizeof(float) * (SKIP ? 320 : 0);
+    size_t with_lut = fixed + sizeof(float) * (size_t)(steps + 2) * LS;
+    const int ngroups = (int)evad_blocks(N, L1_GROUP);
+    int wgs = (ngroups + 7) / 8;                        // at least one 8-wave workgroup per 8 groups ...
+    if (wgs > L1_MAX_WG) wgs = L1_MAX_WG;               // ... at most two per CU: the waves pull groups until none is left
+    wgs = (wgs + 7) / 8 * 8;                            // every XCD gets the same number of workgroups
+    dim3 grid((unsigned)wgs), block(L1_THREADS);
     if (with_lut <= 80 * 1024) {            // two workgroups per CU (160 KiB LDS)
         auto kern = k_l1_conv<CINP, SKIP, true>;
         static size_t attr_set = 0;                 // raise the dynamic-LDS limit once per size (not a stream op)
@@ -132,38 +246,32 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)with_lut);
             attr_set = with_lut;
         }
-        hipLaunchKernelGGL(kern, grid, block, with_lut, st, xin, ell_src, ell_step, deg, lut, root, scale, shift, xskip,
-                           wskip, sscale, sshift, out, N, steps, max_nb);
+        hipLaunchKernelGGL(kern, grid, block, with_lut, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps);
     } else {                                // large radius: LUT stays in global memory / L2
         auto kern = k_l1_conv<CINP, SKIP, false>;
-        hipLaunchKernelGGL(kern, grid, block, fixed, st, xin, ell_src, ell_step, deg, lut, root, scale, shift, xskip,
-                           wskip, sscale, sshift, out, N, steps, max_nb);
+        hipLaunchKernelGGL(kern, grid, block, fixed, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps);
     }
     return evad_last_error();
 }
 
-// conv 1: x0s[N,20] (19 channels + pad) -> y1[N,16]
+// conv 1: x0s[N,20] (19 channels + pad) -> y1[N,16].  lut f32[steps+2][20][16], pre-scaled, row `steps` = self-edge matrix, row `steps+1` = zeros.
 extern "C" int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
-                                const float* lut /* [steps][20][16] */, const float* root /* [20][16] */,
-                                const float* bn_scale, const float* bn_shift, float* y1, int N, int steps,
+                                const float* lut, const float* shift, float* y1, uint32_t* work, int N, int steps,
                                 int max_num_neighbors, void* stream) {
-    if (!x0s || !ell_src || !ell_step || !deg || !lut || !bn_scale || !bn_shift || !y1 || N < 0 || steps < 1)
-        return EVAD_ERR_ARG;
+    if (!x0s || !ell_src || !ell_step || !deg || !lut || !shift || !y1 || !work || N < 0 || steps < 1) return EVAD_ERR_ARG;
     if (N == 0) return EVAD_OK;
-    return launch_l1<20, false>(x0s, ell_src, ell_step, deg, lut, root, bn_scale, bn_shift, nullptr, nullptr, nullptr,
-                                nullptr, y1, N, steps, max_num_neighbors, (hipStream_t)stream);
+    return launch_l1<20, false>(x0s, ell_src, ell_step, deg, lut, shift, nullptr, nullptr, y1, work, N, steps, max_num_neighbors,
+                                (hipStream_t)stream);
 }
 
-// conv 2 + skip branch: y1[N,16], x0s[N,20] -> y2[N,16]
+// conv 2 + skip branch: y1[N,16], x0s[N,20] -> y2[N,16].  lut f32[steps+2][16][16] and wskip f32[20][16] pre-scaled,
+// shift = folded BN shift of the conv + folded BN shift of the skip branch.
 extern "C" int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t* ell_src, const uint16_t* ell_step,
-                                const int32_t* deg, const float* lut /* [steps][16][16] */, const float* root /* [16][16] */,
-                                const float* bn_scale, const float* bn_shift, const float* wskip /* [20][16] */,
-                                const float* skip_scale, const float* skip_shift, float* y2, int N, int steps,
-                                int max_num_neighbors, void* stream) {
-    if (!y1 || !x0s || !ell_src || !ell_step || !deg || !lut || !bn_scale || !bn_shift || !wskip ||
-        !skip_scale || !skip_shift || !y2 || N < 0 || steps < 1)
+                                const int32_t* deg, const float* lut, const float* wskip, const float* shift, float* y2,
+                                uint32_t* work, int N, int steps, int max_num_neighbors, void* stream) {
+    if (!y1 || !x0s || !ell_src || !ell_step || !deg || !lut || !shift || !wskip || !y2 || !work || N < 0 || steps < 1)
         return EVAD_ERR_ARG;
     if (N == 0) return EVAD_OK;
-    return launch_l1<16, true>(y1, ell_src, ell_step, deg, lut, root, bn_scale, bn_shift, x0s, wskip, skip_scale,
-                               skip_shift, y2, N, steps, max_num_neighbors, (hipStream_t)stream);
+    return launch_l1<16, true>(y1, ell_src, ell_step, deg, lut, shift, x0s, wskip, y2, work, N, steps, max_num_neighbors,
+                               (hipStream_t)stream);
 }

@@ -57,3 +57,13 @@ def pad_rows(w, rows):
     out = torch.zeros(rows, w.shape[1])
     out[: w.shape[0]] = w
     return out.contiguous()
+
+
+def quad_row_order(w):
+    """Re-order the input-channel rows of f32[..., Cin, 16] weight matrices (Cin = 16 or 20) for the event-level conv
+    kernel, whose 4 lanes per destination split the input channels: row i*4 + j = i-th channel of lane j = channel 4j+i
+    (i < 4) or 16+j (i = 4)."""
+    cin = w.shape[-2]
+    assert cin in (16, 20)
+    order = [4 * j + i for i in range(4) for j in range(4)] + ([16 + j for j in range(4)] if cin == 20 else [])
+    return w[..., order, :].contiguous()

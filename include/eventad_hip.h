@@ -111,16 +111,20 @@ int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32
 
 /* ---- (C) first Layer on the event graph: replaces Layer.forward for conv_block1 --------------- */
 /* (conv.py:59-72 = ConvBlock :10-28 + ConvBlockWithSkip :31-56 over MySplineConv.message_lut,
- * spline_conv.py:39-78).  lut = MySplineConv.lut_weights re-ordered by spiral step, [steps][Cin_pad][16];
- * root = conv.lin.weight^T [Cin_pad][16], or NULL when the caller appended lut[steps] = lut[0] + root (the matrix of the
- * self edge that opens every ELL row: one mat-vec less per node); bn_* = folded eval BatchNorm (components.py:9-12). */
+ * spline_conv.py:39-78).  lut = MySplineConv.lut_weights re-ordered by spiral step, f32[steps+2][Cin_pad][16], every
+ * output column pre-multiplied by the folded eval-mode BatchNorm scale of that channel (components.py:9-12); row `steps`
+ * = (lut[0] + conv.lin.weight^T) * scale, the matrix of the self edge that opens every ELL row (root weight,
+ * spline_conv.py:72-73); row `steps + 1` = zeros (idle lanes multiply by it instead of branching).  shift = folded BatchNorm shift (conv 2: of the conv plus of the skip branch); wskip =
+ * lin.mlp.weight^T [20][16] times the skip BatchNorm's scale.  The input-channel rows of every matrix are stored in the
+ * order [i][j] (row i*4 + j = channel 4j+i for i < 4, channel 16+j for i = 4): the 4 lanes of a destination split the
+ * input channels.  work u32[256]: per-XCD work counters, one per 128-byte line, ZERO on entry (the waves pull groups of
+ * 64 destinations from them), left non-zero; each call needs its own zeroed 256 words.  max_num_neighbors must be 16. */
 int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
-                     const float* lut, const float* root, const float* bn_scale, const float* bn_shift, float* y1,
-                     int N, int steps, int max_num_neighbors, void* stream);
+                     const float* lut, const float* shift, float* y1, uint32_t* work, int N, int steps,
+                     int max_num_neighbors, void* stream);
 int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t* ell_src, const uint16_t* ell_step,
-                     const int32_t* deg, const float* lut, const float* root, const float* bn_scale,
-                     const float* bn_shift, const float* wskip, const float* skip_scale, const float* skip_shift,
-                     float* y2, int N, int steps, int max_num_neighbors, void* stream);
+                     const int32_t* deg, const float* lut, const float* wskip, const float* shift, float* y2,
+                     uint32_t* work, int N, int steps, int max_num_neighbors, void* stream);
 
 /* ---- (D) sampling_skip + Pooling.forward: replaces net.py:15-17,200-228 + pooling.py:51-97 ------ */
 /* Slot table over S = nx*ny*(B+1) voxel slots: feat u32[S,Ca+Cm], sums u64[S,2], tsum 8 bytes[S] (2^-40 fixed point),
