@@ -6,7 +6,8 @@
 //     y2    = ReLU( BN(out2) + BN_skip(W_skip x_i) )                                            (conv 2)
 // The reference gathers LUT[dx,dy] into an [E,Cin,Cout] temporary (36.6 GB in its own comment,
 // spline_conv.py:43-44) and scatter-adds.  Here every destination owns <=16 contiguous ELL slots
-// (graph.hip), the LUT (one Cin x 16 matrix per spiral step, 49 steps at r=3) lives in LDS, and the 4 lanes of a
+// (graph.hip), the LUT (one Cin x 16 matrix per spiral step, 49 steps at r=3) lives in LDS (at larger radii: its inner
+// rings, as many as fit), and the 4 lanes of a
 // destination split the INPUT channels: no atomics, no temporary.
 //
 // Weights arrive pre-multiplied by the folded eval-mode BatchNorm scale of their output column (host side:
@@ -91,10 +92,11 @@ template <int S> __device__ __forceinline__ int comp4(const int4& v) { return S 
 // Branch-free on purpose: a load inside a divergent branch lands in a temporary that the compiler can only copy into
 // the ring buffer after waiting for ALL outstanding loads, which serialises the prefetch.  Slots past the row's degree
 // multiply a cached row (the destination's own) by the all-zero matrix LUT[steps + 1] instead.
-template <int CINP, int KL, int S>
+template <int CINP, int KL, int S, bool ALL_IN_LDS>
 __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float (&xe)[4], const int4& sv, const uint2& cv,
                                         const int4& sv2, int b, bool last, bool half, int d, int d2, int j, int safe, int safe2,
-                                        const float* __restrict__ xin, const float* __restrict__ wbase, const int (&rot)[4], int steps) {
+                                        const float* __restrict__ xin, const float* __restrict__ wlds, const float* __restrict__ wglb,
+                                        int nlds, const int (&rot)[4], int steps) {
     constexpr int LS = CINP * 16;
     const int e = 4 * b + S;
     const int pair = quad_bcast<0>((int)(S & 2 ? cv.y : cv.x));
@@ -106,30 +108,40 @@ __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float
     int nnext = quad_bcast<0>(comp4<S>(sv2));
     nnext = S < d2 ? nnext : safe2;
     // `half` (uniform): the row's last block holds at most two live slots -- slots 2 and 3 only refill their buffers
-    if (S < 2 || !half) l1_fma<KL>(acc, xv[S], xe[S], wbase + (size_t)cell * LS, rot);
+    if (S < 2 || !half) {
+        if (ALL_IN_LDS) l1_fma<KL>(acc, xv[S], xe[S], wlds + cell * LS, rot);
+        else {
+            // Large search radius: only the first `nlds` spiral steps (the inner rings, where the <= 16 neighbours of a dense
+            // window lie) + the two special matrices are in LDS.  A slot in which ANY lane of the wave needs an outer ring
+            // reads its matrices from global memory (L2) for the whole wave -- rare, and wave-uniform, so no lane diverges.
+            const bool outer = cell >= nlds && cell < steps;
+            if (__any(outer)) l1_fma<KL>(acc, xv[S], xe[S], wglb + (size_t)cell * LS, rot);
+            else              l1_fma<KL>(acc, xv[S], xe[S], wlds + (cell < nlds ? cell : nlds + cell - steps) * LS, rot);
+        }
+    }
     // the refill comes after the products that read the buffer, so the old row needs no copy
     l1_load_row<CINP>(xin, last ? nnext : nsrc, j, xv[S], xe[S]);
 }
 
-template <int CINP, bool SKIP, bool LUT_IN_LDS>
+template <int CINP, bool SKIP, bool ALL_IN_LDS>
 __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
                                                  const uint16_t* __restrict__ ell_step, const int* __restrict__ deg,
                                                  const float* __restrict__ lut, const float* __restrict__ shift,
                                                  const float* __restrict__ xskip, const float* __restrict__ wskip,
-                                                 float* __restrict__ out, unsigned* __restrict__ work, int N, int steps) {
+                                                 float* __restrict__ out, unsigned* __restrict__ work, int N, int steps, int nlds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KL = CINP == 20 ? 5 : 4;                // input channels per lane
     constexpr int LS = CINP * 16;                         // floats per LUT matrix
     static_assert(CINP == 20 || CINP == 16, "lane/channel map is written for 20 or 16 input channels");
     float* s_skip = smem;                                 // [5][4][16] (SKIP only)
-    float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [steps+2][KL][4][16]
+    float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [nlds+2][KL][4][16]: spiral steps 0..nlds-1, self-edge matrix, zeros
     const int tid = threadIdx.x;
     // ---- once per workgroup: LUT and skip weights (already in the [i][j][16] row order) into LDS, 16 bytes per lane and trip
-    if (LUT_IN_LDS) {
+    {
         const float4* g4 = (const float4*)lut;
         float4* s4 = (float4*)s_lut;
-        const int n4 = (steps + 2) * LS / 4;
-        for (int t = tid; t < n4; t += L1_THREADS) s4[t] = g4[t];
+        const int n4 = nlds * LS / 4, m4 = 2 * LS / 4, skip4 = (steps - nlds) * LS / 4;
+        for (int t = tid; t < n4 + m4; t += L1_THREADS) s4[t] = g4[t < n4 ? t : t + skip4];
     }
     if (SKIP) { if (tid < 80) ((float4*)s_skip)[tid] = ((const float4*)wskip)[tid]; }
     __syncthreads();                                      // the only workgroup barrier: from here on every wave is on its own
@@ -138,7 +150,8 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
 #pragma unroll
     for (int s = 0; s < 4; ++s) rot[s] = ((s + a) & 3) * 4;
     const float4 sh = *(const float4*)(shift + 4 * j);
-    const float* wbase = (LUT_IN_LDS ? (const float*)s_lut : lut) + j * 16;
+    const float* wlds = s_lut + j * 16;
+    const float* wglb = lut + j * 16;
     // Work items: groups of 64 consecutive destinations, handed out by one counter per XCD (blockIdx & 7: workgroups are dealt
     // round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so the
     // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
 #pragma unroll 1
             for (int b = 0; 4 * b < dmax; ++b) {
                 const bool last = 4 * (b + 1) >= dmax, half = dmax - 4 * b <= 2;
-#define L1_E(S) l1_edge<CINP, KL, S>(acc, xv, xe, sv, cv, sv2, b, last, half, d, d2, j, safe, safe2, xin, wbase, rot, steps)
+#define L1_E(S) l1_edge<CINP, KL, S, ALL_IN_LDS>(acc, xv, xe, sv, cv, sv2, b, last, half, d, d2, j, safe, safe2, xin, wlds, wglb, nlds, rot, steps)
                 L1_E(0); L1_E(1); L1_E(2); L1_E(3);
 #undef L1_E
                 sv.x = quad_rotate(sv.x); sv.y = quad_rotate(sv.y); sv.z = quad_rotate(sv.z); sv.w = quad_rotate(sv.w);
@@ -232,24 +245,24 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
                      int max_nb, hipStream_t st) {
     constexpr int LS = CINP * 16;
     if (max_nb != 16) return EVAD_ERR_ARG;              // an ELL row is read as 4 x int4 + 4 x uint2
-    size_t fixed = sizeof(float) * (SKIP ? 320 : 0);
-    size_t with_lut = fixed + sizeof(float) * (size_t)(steps + 2) * LS;
+    const size_t fixed = sizeof(float) * (SKIP ? 320 : 0), budget = 80 * 1024;   // two workgroups per CU (160 KiB LDS)
+    int nlds = (int)((budget - fixed) / (sizeof(float) * LS)) - 2;               // spiral steps whose matrices fit beside the 2 special ones
+    if (nlds > steps) nlds = steps;
+    const size_t lds = fixed + sizeof(float) * (size_t)(nlds + 2) * LS;
     const int ngroups = (int)evad_blocks(N, L1_GROUP);
     int wgs = (ngroups + 7) / 8;                        // at least one 8-wave workgroup per 8 groups ...
     if (wgs > L1_MAX_WG) wgs = L1_MAX_WG;               // ... at most two per CU: the waves pull groups until none is left
     wgs = (wgs + 7) / 8 * 8;                            // every XCD gets the same number of workgroups
     dim3 grid((unsigned)wgs), block(L1_THREADS);
-    if (with_lut <= 80 * 1024) {            // two workgroups per CU (160 KiB LDS)
+    static size_t attr_set[2] = {0, 0};                 // raise the dynamic-LDS limit once per size (not a stream op)
+    if (nlds == steps) {
         auto kern = k_l1_conv<CINP, SKIP, true>;
-        static size_t attr_set = 0;                 // raise the dynamic-LDS limit once per size (not a stream op)
-        if (attr_set < with_lut) {
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)with_lut);
-            attr_set = with_lut;
-        }
-        hipLaunchKernelGGL(kern, grid, block, with_lut, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps);
-    } else {                                // large radius: LUT stays in global memory / L2
+        if (attr_set[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = lds; }
+        hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
+    } else {                                // large radius: inner rings in LDS, outer rings read from global memory / L2
         auto kern = k_l1_conv<CINP, SKIP, false>;
-        hipLaunchKernelGGL(kern, grid, block, fixed, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps);
+        if (attr_set[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = lds; }
+        hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
     }
     return evad_last_error();
 }
