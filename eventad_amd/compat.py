@@ -6,6 +6,7 @@ to this package --
     from dagr.model.networks.ema import ModelEMA                    (utils/model.py:5)
     from dagr.utils.buffers import format_data                      (utils/train.py)
     import ev_graph_cuda                                            (src/dagr/graph/utils.py:2)
+    import asy_tools                                                (src/dagr/asynchronous/*.py)
 so the reference's train.py / test.py / utils run unchanged on top of the HIP path."""
 import importlib
 import sys
@@ -31,6 +32,7 @@ _ALIASES = {
     "dagr.model.networks.ema": "eventad_amd.dagr.model.networks.ema",
     "dagr.graph": "eventad_amd.dagr.graph",
     "dagr.graph.ev_graph": "eventad_amd.dagr.graph.ev_graph",
+    "asy_tools": "eventad_amd.dagr.asynchronous.asy_tools",        # src/dagr/asynchronous/asy_tools (CUDA extension)
 }
 
 

@@ -258,6 +258,21 @@ int eventad_bn_relu_maxpool(const float* in, const float* scale, const float* sh
 /* image f32[B,3,H,W] -> f32[B,H,W,4] (zero 4th channel) so the 7x7 stem reads float4s. */
 int eventad_image_to_nhwc4(const float* in, float* out, int B, int H, int W, void* stream);
 
+/* ---- (H) asynchronous (event-by-event) inference: replaces the CUDA extension `asy_tools` ---------------------- */
+/* (reference src/dagr/asynchronous/asy_tools/main.cu:14-188, pybind :239-244).  indices i64[K] list the rows to touch.
+ * masked_isdiff(indices, x_old, x_new, atol, rtol) :96-125 (kernel :14-41): indices[i] <- -1 unless row indices[i] of
+ * x_old / x_new f32[*, C] differs in some channel by more than atol + rtol * x_new; the caller drops the -1 entries. */
+int eventad_masked_isdiff(int64_t* indices, const float* x_old, const float* x_new, int K, int C, float atol, float rtol,
+                          void* stream);
+/* masked_inplace_BN(indices, x, x_out, running_mean, running_var, weight, bias, eps) :69-94 (kernel :43-67). */
+int eventad_masked_inplace_bn(const int64_t* indices, const float* x, float* x_out, const float* running_mean,
+                              const float* running_var, const float* weight, const float* bias, int K, int C, float eps,
+                              void* stream);
+/* masked_lin(indices, x_in, x_out, weight, bias, add) :215-236 and masked_lin_no_bias :190-212 (bias == NULL);
+ * kernels :128-188.  weight f32[Cout, Cin]; add != 0 accumulates onto x_out. */
+int eventad_masked_lin(const int64_t* indices, const float* x_in, float* x_out, const float* weight, const float* bias,
+                       int K, int Cin, int Cout, int add, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

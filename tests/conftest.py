@@ -22,7 +22,8 @@ def pytest_sessionstart(session):
     runs the tests before `__graft_entry__.build()` (hipcc cross-compiles gfx950 without a GPU)."""
     so = os.path.join(ROOT, "eventad_amd", "lib", "libeventad_hip.so")
     ora = os.path.join(ROOT, "oracle", "_build", "libgraph_ref.so")
-    if not (os.path.exists(so) and os.path.exists(ora)):
+    ora2 = os.path.join(ROOT, "oracle", "_build", "libasy_ref.so")
+    if not (os.path.exists(so) and os.path.exists(ora) and os.path.exists(ora2)):
         import subprocess
         subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "eventad_amd", "csrc")], check=False)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=False)
