@@ -1,0 +1,220 @@
+// eventad_amd/csrc/bwd.hip -- backward of the event-level LUT spline convolution (fine-tuning the DAGR backbone).
+//
+// Forward (reference MySplineConv, src/dagr/model/layers/spline_conv.py:39-78; csrc/layer1.hip):
+//     out_i = sum_{j->i} LUT[cell_ji]^T x_j        (the self edge's matrix LUT[steps] = LUT[0] + W_root carries the root term)
+// Backward, given g = dL/d out  (the reference gets both from autograd over its gather + scatter-add, spline_conv.py:44-47,68):
+//     dx_j      = sum_{i : j->i} LUT[cell_ji] g_i                      (gather over the TRANSPOSED graph)
+//     dLUT[c]   = sum_{j->i, cell_ji = c} x_j (x) g_i                  (one Cin x 16 outer-product sum per spiral step)
+// and the host maps dLUT to dL/d weight[25, Cin, 16] and dL/d root through the (linear) LUT construction.
+//
+// No float atomics anywhere, so both results are bitwise reproducible:
+//  * the transposed adjacency (out-edges per source) is built with integer atomics for the COUNTS only; the arrival order
+//    they leave inside a source's list is then replaced by a rank sort on (destination, slot), so the list -- and with
+//    it the summation order of dx -- is the same in every run;
+//  * dLUT is accumulated in two ordered stages: each workgroup walks its destinations in order, every thread owning one
+//    (channel, output) element of all matrices in a private LDS column; the workgroups' partial tables are then summed in
+//    workgroup order.
+#include "common.h"
+
+int evad_exclusive_scan(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, hipStream_t st);   // graph.hip
+
+// ------------------------------------------------------------------------------------------------ transposed adjacency
+__global__ void k_out_count(const int* __restrict__ ell_src, const int* __restrict__ deg, int N, unsigned* __restrict__ cnt,
+                            unsigned short* __restrict__ arrival) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * 16) return;
+    const int i = (int)(t >> 4), slot = (int)(t & 15);
+    if (slot >= deg[i]) return;
+    const unsigned a = atomicAdd(&cnt[ell_src[t]], 1u);
+    arrival[t] = (unsigned short)min(a, 65535u);
+}
+
+__global__ void k_out_scatter(const int* __restrict__ ell_src, const int* __restrict__ deg, int N, const unsigned* __restrict__ start,
+                              const unsigned short* __restrict__ arrival, int* __restrict__ tmp) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * 16) return;
+    const int i = (int)(t >> 4), slot = (int)(t & 15);
+    if (slot >= deg[i]) return;
+    tmp[start[ell_src[t]] + arrival[t]] = (int)t;          // key = destination * 16 + slot
+}
+
+// one thread per list position: rank of its key inside the source's list (lists are short: mean = mean degree)
+__global__ void k_out_rank(const unsigned* __restrict__ start, const int* __restrict__ ell_src, const int* __restrict__ tmp,
+                           int* __restrict__ out_edge, int N) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long long)start[N]) return;                  // E = start[N] is known on the device only
+    const int key = tmp[p];
+    const int src = ell_src[key];
+    const unsigned s0 = start[src], s1 = start[src + 1];
+    unsigned rank = 0;
+    for (unsigned c = s0; c < s1; ++c) rank += (tmp[c] < key);
+    out_edge[s0 + rank] = key;
+}
+
+// out_start u32[N+1], out_edge i32[E_max = 16N] (key = destination * 16 + slot, ascending inside a source's list).
+// scratch: cnt u32[N+1], scan_tmp u32[N/2048+2], arrival u16[16N], tmp i32[16N].  A source may have at most 65535
+// out-edges (its arrival index is kept in 16 bits).
+extern "C" int eventad_ell_transpose(const int32_t* ell_src, const int32_t* deg, int N, uint32_t* out_start, int32_t* out_edge,
+                                     uint32_t* cnt, uint32_t* scan_tmp, uint16_t* arrival, int32_t* tmp, void* stream) {
+    if (!ell_src || !deg || !out_start || !out_edge || !cnt || !scan_tmp || !arrival || !tmp || N < 0) return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    evad_zero_async(cnt, sizeof(uint32_t) * ((size_t)N + 1), st);
+    const long long T = (long long)N * 16;
+    hipLaunchKernelGGL(k_out_count, dim3(evad_blocks(T, 256)), dim3(256), 0, st, ell_src, deg, N, cnt, (unsigned short*)arrival);
+    int rc = evad_exclusive_scan(cnt, out_start, scan_tmp, N, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_out_scatter, dim3(evad_blocks(T, 256)), dim3(256), 0, st, ell_src, deg, N, out_start,
+                       (const unsigned short*)arrival, tmp);
+    // E is only known on the device (out_start[N]); launch over the bound 16N, positions past E fall out of every list
+    hipLaunchKernelGGL(k_out_rank, dim3(evad_blocks(T, 256)), dim3(256), 0, st, out_start, ell_src, tmp, out_edge, N);
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------ dL/dx
+// One quad per source; lane q of the quad owns input channels {4q..4q+3} (+ 16+q for Cin = 20), exactly as the forward
+// kernel, and reads its rows of LUT[cell] (row order [i][j], see eventad_amd/spline.py::quad_row_order) from LDS.
+template <int CINP>
+__global__ __launch_bounds__(256) void k_conv_bwd_data(const float* __restrict__ g, const unsigned* __restrict__ out_start,
+                                                       const int* __restrict__ out_edge, const uint16_t* __restrict__ ell_step,
+                                                       const float* __restrict__ lut, float* __restrict__ dx, int N, int steps) {
+    extern __shared__ __attribute__((aligned(16))) float s_lut[];
+    constexpr int KL = CINP == 20 ? 5 : 4, LS = CINP * 16;
+    for (int t = threadIdx.x; t < (steps + 1) * LS / 4; t += 256) ((float4*)s_lut)[t] = ((const float4*)lut)[t];
+    __syncthreads();
+    const int j = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    if (j >= N) return;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned p0 = out_start[j], p1 = out_start[j + 1];
+    for (unsigned p = p0; p < p1; ++p) {
+        const int key = out_edge[p];
+        const int i = key >> 4, slot = key & 15;
+        const int cell = slot == 0 ? steps : (int)ell_step[key];
+        const float4* gr = (const float4*)(g + (size_t)i * 16);
+        const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3];
+        const float gv[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+        const float* w = s_lut + cell * LS + q * 16;
+#pragma unroll
+        for (int k = 0; k < KL; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) s = fmaf(w[k * 64 + o], gv[o], s);
+            acc[k] += s;
+        }
+    }
+    float* d = dx + (size_t)j * CINP;
+    *(float4*)(d + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (CINP == 20) d[16 + q] = acc[4];
+}
+
+// lut f32[steps+1][Cin_pad][16] in the [i][j] row order of the forward kernel (row `steps` = self-edge matrix); g f32[N,16];
+// dx f32[N, Cin_pad].  cin_pad = 20 or 16.  (steps + 1) * Cin_pad * 64 bytes of LDS: radius <= 5 px.
+extern "C" int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_start, const int32_t* out_edge, const uint16_t* ell_step,
+                                        const float* lut, float* dx, int N, int steps, int cin_pad, void* stream) {
+    if (!g || !out_start || !out_edge || !ell_step || !lut || !dx || N < 0 || steps < 1 || (cin_pad != 20 && cin_pad != 16)) return EVAD_ERR_ARG;
+    const size_t lds = sizeof(float) * (size_t)(steps + 1) * cin_pad * 16;
+    if (lds > 150 * 1024) return EVAD_ERR_ARG;             // larger search radii: not implemented for the backward pass
+    if (N == 0) return EVAD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    static size_t attr[2] = {0, 0};
+    if (cin_pad == 20) {
+        auto kern = k_conv_bwd_data<20>;
+        if (attr[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
+        hipLaunchKernelGGL(kern, dim3(evad_blocks(N, 64)), dim3(256), lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
+    } else {
+        auto kern = k_conv_bwd_data<16>;
+        if (attr[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
+        hipLaunchKernelGGL(kern, dim3(evad_blocks(N, 64)), dim3(256), lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
+    }
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------ dL/dLUT
+// Stage 1: workgroup w walks destinations [w*chunk, (w+1)*chunk) in order; thread t = (k, o) owns element (k, o) of every
+// matrix: acc[cell][t] lives in LDS, touched by that thread only.  Rows x_src and g_dst of 16 edges at a time are staged
+// in LDS by the workgroup.  Stage 2: partial tables summed in workgroup order.
+#define BW_EDGES 32
+template <int CINP>
+__global__ __launch_bounds__(CINP * 16) void k_conv_bwd_weight(const float* __restrict__ x, const float* __restrict__ g,
+                                                               const int* __restrict__ ell_src, const uint16_t* __restrict__ ell_step,
+                                                               const int* __restrict__ deg, float* __restrict__ partial, int N,
+                                                               int steps, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int T = CINP * 16;
+    float* s_acc = smem;                                   // [steps+1][T]
+    float* s_x = s_acc + (size_t)(steps + 1) * T;          // [BW_EDGES][CINP]
+    float* s_g = s_x + BW_EDGES * CINP;                    // [BW_EDGES][16]
+    int* s_cell = (int*)(s_g + BW_EDGES * 16);             // [BW_EDGES]
+    const int tid = threadIdx.x, k = tid >> 4, o = tid & 15;
+    for (int c = 0; c <= steps; ++c) s_acc[c * T + tid] = 0.f;
+    const int n0 = blockIdx.x * chunk, n1 = min(n0 + chunk, N);
+    // flat edge walk over the chunk's ELL slots, BW_EDGES slots per round (slots past a row's degree are skipped)
+    for (long long e0 = (long long)n0 * 16; e0 < (long long)n1 * 16; e0 += BW_EDGES) {
+        __syncthreads();
+        if (tid < BW_EDGES) {
+            const long long e = e0 + tid;
+            const int i = (int)(e >> 4), slot = (int)(e & 15);
+            int cell = -1;
+            if (i < n1 && slot < deg[i]) cell = slot == 0 ? steps : (int)ell_step[e];
+            s_cell[tid] = cell;
+        }
+        __syncthreads();
+        for (int t = tid; t < BW_EDGES * CINP; t += T) {
+            const int r = t / CINP, c = t - r * CINP;
+            if (s_cell[r] >= 0) s_x[t] = x[(size_t)ell_src[e0 + r] * CINP + c];
+        }
+        for (int t = tid; t < BW_EDGES * 16; t += T) {
+            const int r = t >> 4;
+            if (s_cell[r] >= 0) s_g[t] = g[(size_t)((e0 + r) >> 4) * 16 + (t & 15)];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < BW_EDGES; ++r) {
+            const int cell = s_cell[r];
+            if (cell >= 0) s_acc[cell * T + tid] = fmaf(s_x[r * CINP + k], s_g[r * 16 + o], s_acc[cell * T + tid]);
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * (steps + 1) * T;
+    for (int c = 0; c <= steps; ++c) out[c * T + tid] = s_acc[c * T + tid];
+}
+
+__global__ void k_sum_partials(const float* __restrict__ partial, int n_part, int len, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= len) return;
+    float s = 0.f;
+    for (int p = 0; p < n_part; ++p) s += partial[(size_t)p * len + t];
+    out[t] = s;
+}
+
+// x f32[N, Cin_pad] (the conv's input rows), g f32[N,16]; dlut f32[steps+1][Cin_pad][16] in NATURAL channel order;
+// partial = scratch f32[n_part][steps+1][Cin_pad][16] with n_part = eventad_l1_conv_bwd_weight_parts(N).
+extern "C" int eventad_l1_conv_bwd_weight_parts(int N) {
+    int parts = (N + 255) / 256;
+    return parts < 1 ? 1 : (parts > 1024 ? 1024 : parts);
+}
+
+extern "C" int eventad_l1_conv_bwd_weight(const float* x, const float* g, const int32_t* ell_src, const uint16_t* ell_step,
+                                          const int32_t* deg, float* partial, float* dlut, int N, int steps, int cin_pad,
+                                          void* stream) {
+    if (!x || !g || !ell_src || !ell_step || !deg || !partial || !dlut || N < 0 || steps < 1 || (cin_pad != 20 && cin_pad != 16))
+        return EVAD_ERR_ARG;
+    const int T = cin_pad * 16;
+    const size_t lds = sizeof(float) * ((size_t)(steps + 1) * T + BW_EDGES * (cin_pad + 16)) + sizeof(int) * BW_EDGES;
+    if (lds > 150 * 1024) return EVAD_ERR_ARG;             // larger search radii: not implemented for the backward pass
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = eventad_l1_conv_bwd_weight_parts(N);
+    const int chunk = (N + parts - 1) / parts > 0 ? (N + parts - 1) / parts : 1;
+    static size_t attr[2] = {0, 0};
+    if (cin_pad == 20) {
+        auto kern = k_conv_bwd_weight<20>;
+        if (attr[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
+        hipLaunchKernelGGL(kern, dim3(parts), dim3(T), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, chunk);
+    } else {
+        auto kern = k_conv_bwd_weight<16>;
+        if (attr[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
+        hipLaunchKernelGGL(kern, dim3(parts), dim3(T), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, chunk);
+    }
+    const int len = (steps + 1) * T;
+    hipLaunchKernelGGL(k_sum_partials, dim3(evad_blocks(len, 256)), dim3(256), 0, st, partial, parts, len, dlut);
+    return evad_last_error();
+}

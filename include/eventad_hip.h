@@ -273,6 +273,26 @@ int eventad_masked_inplace_bn(const int64_t* indices, const float* x, float* x_o
 int eventad_masked_lin(const int64_t* indices, const float* x_in, float* x_out, const float* weight, const float* bias,
                        int K, int Cin, int Cout, int add, void* stream);
 
+/* ---- (I) backward of the event-level LUT spline convolution (fine-tuning the backbone) ------------------------- */
+/* The reference obtains these from autograd over MySplineConv's gather + scatter-add (spline_conv.py:39-78).  All of
+ * them are free of float atomics: bitwise reproducible.
+ * eventad_ell_transpose: out-edges per source from the ELL adjacency.  out_start u32[N+1], out_edge i32[16N] (key =
+ * destination * 16 + slot, ascending inside a source's list; E = out_start[N] entries are valid).  Scratch: cnt
+ * u32[N+1], scan_tmp u32[N/2048+2], arrival u16[16N], tmp i32[16N]. */
+int eventad_ell_transpose(const int32_t* ell_src, const int32_t* deg, int N, uint32_t* out_start, int32_t* out_edge,
+                          uint32_t* cnt, uint32_t* scan_tmp, uint16_t* arrival, int32_t* tmp, void* stream);
+/* dx_j = sum over out-edges (j -> i) of LUT[cell] g_i.  g f32[N,16] = dL/d(conv output); lut f32[steps+1][cin_pad][16] with
+ * the input-channel rows in the forward kernel's [i][j] order, row `steps` = self-edge matrix; dx f32[N, cin_pad];
+ * cin_pad = 20 or 16; (steps+1) * cin_pad * 64 bytes must fit in LDS (search radius <= 5 px), else -1. */
+int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_start, const int32_t* out_edge, const uint16_t* ell_step,
+                             const float* lut, float* dx, int N, int steps, int cin_pad, void* stream);
+/* dlut[c] = sum over edges with spiral step c of x_src (x) g_dst, f32[steps+1][cin_pad][16] in natural channel order (row
+ * `steps` = the self edges: gradient of LUT[0] + W_root).  partial = scratch f32[eventad_l1_conv_bwd_weight_parts(N)]
+ * [steps+1][cin_pad][16]. */
+int eventad_l1_conv_bwd_weight_parts(int N);
+int eventad_l1_conv_bwd_weight(const float* x, const float* g, const int32_t* ell_src, const uint16_t* ell_step,
+                               const int32_t* deg, float* partial, float* dlut, int N, int steps, int cin_pad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
