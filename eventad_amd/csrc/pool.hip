@@ -37,8 +37,9 @@ __device__ __forceinline__ int pool_slot_of(float px, float py, float pt, int b,
     return (int)(sl < 0 ? 0 : (sl >= S ? S - 1 : sl));
 }
 
-// 16 lanes per node, 16 nodes per 256-thread block.
-template <bool MEAN>
+// 16 lanes per node, 16 nodes per 256-thread block.  Max aggregation through order-preserving integer atomicMax (exact and
+// order independent); the mean aggregation of pool4 only takes the slot bookkeeping from here (Ca = Cm = 0) and sums in
+// k_pool_mean_gather.
 __global__ __launch_bounds__(256) void k_pool_scatter(
     const float* __restrict__ xa, int lda, int Ca, const float* __restrict__ map, int map_h, int map_w, int Cm,
     const float* __restrict__ npos, const int* __restrict__ npix, const int* __restrict__ nbatch,
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
     unsigned* frow = feat + (size_t)slot * C;
     for (int c = lane; c < Ca; c += 16) {
         float v = xa[(size_t)node * lda + c];
-        if (MEAN) atomicAdd((float*)frow + c, v); else atomicMax(frow + c, evad_f2ord(v));
+        atomicMax(frow + c, evad_f2ord(v));
     }
     if (Cm > 0) {
         int x0, y0; float fx, fy;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
             if (vx1 && vy0) v += p01[c] * w01;
             if (vx0 && vy1) v += p10[c] * w10;
             if (vx1 && vy1) v += p11[c] * w11;
-            if (MEAN) atomicAdd((float*)frow + Ca + c, v); else atomicMax(frow + Ca + c, evad_f2ord(v));
+            atomicMax(frow + Ca + c, evad_f2ord(v));
         }
     }
     if (lane == 0) {
@@ -178,14 +179,14 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
     dim3 grid(evad_blocks(n_max, 16)), block(256);
     if (mean_aggr) {
         if (!n_dev || key_s || C > 128) return EVAD_ERR_ARG;                     // pooled levels only
-        hipLaunchKernelGGL(k_pool_scatter<false>, grid, block, 0, st, xa, lda, 0, map_nhwc, map_h, map_w, 0, npos, npix,
+        hipLaunchKernelGGL(k_pool_scatter, grid, block, 0, st, xa, lda, 0, map_nhwc, map_h, map_w, 0, npos, npix,
                            nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
                            tsum, cnt, maxidx, node_slot, flags, rowptr, csr_src, bitmap);
         hipLaunchKernelGGL(k_pool_mean_gather, dim3(evad_blocks(S, 4)), dim3(256), 0, st, xa, lda, Ca, map_nhwc, map_h, map_w,
                            Cm, npos, nbatch, node_slot, n_max, n_dev, W, H, S, (float*)feat);
     }
     else
-        hipLaunchKernelGGL(k_pool_scatter<false>, grid, block, 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, npix,
+        hipLaunchKernelGGL(k_pool_scatter, grid, block, 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, npix,
                            nbatch, key_s, nidx, n_max, n_dev, W, H, vsx, vsy, nx, ny, S, feat, (unsigned long long*)sums,
                            tsum, cnt, maxidx, node_slot, flags, rowptr, csr_src, bitmap);
     return evad_last_error();

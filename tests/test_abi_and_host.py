@@ -133,3 +133,33 @@ def test_unsupported_network_flags_raise():
     for flag in (["--keep_temporal_ordering"], ["--no_events"], ["--img_net", "resnet18"], ["--pooling_aggr", "mean"]):
         with pytest.raises(NotImplementedError):
             DAGR(parse_eventad_args(flag), height=64, width=64)
+
+
+def test_shim_serves_the_reference_import_names_without_editing_train_py(tmp_path):
+    """`PYTHONPATH=<repo>/shim python train.py`: a script directory that has its own `models/EventAD.py` and
+    `config/eventad_config.py` (as the reference's has) must still get this package's modules."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for pkg, mod in (("models", "EventAD"), ("config", "eventad_config")):
+        d = tmp_path / pkg
+        d.mkdir()
+        (d / "__init__.py").write_text("")
+        (d / (mod + ".py")).write_text("raise ImportError('the script directory copy must be shadowed')\n")
+    script = tmp_path / "train.py"
+    script.write_text(
+        "import sys\n"
+        "from config.eventad_config import parse_eventad_args\n"
+        "from models.EventAD import EventADModel\n"
+        "from dagr.model.networks.dagr import DAGR\n"
+        "from dagr.model.networks.ema import ModelEMA\n"
+        "from dagr.utils.buffers import format_data\n"
+        "import ev_graph_cuda, asy_tools\n"
+        "from utils.test import collect_predictions\n"
+        "a = parse_eventad_args([])\n"
+        "print('OK', EventADModel.__module__, DAGR.__module__, a.radius, ev_graph_cuda.fill_edges_cuda.__name__)\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "shim"))
+    out = subprocess.run([sys.executable, str(script)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "OK eventad_amd.models.EventAD eventad_amd.dagr.model.networks.dagr 0.01 fill_edges_cuda" in out.stdout

@@ -152,3 +152,58 @@ def test_workspace_of_a_larger_batch_is_reused_for_a_smaller_one():
     fresh = run(NativeBackbone(weights.random_graph_state(), W, H, dev), small)
     assert n == int(fresh["out4"]["n_dev"].item()) and torch.equal(x_reused, fresh["out4"]["x"][:n])
     assert nb.check_flags() & ~1 == 0
+
+
+def test_rarely_taken_kernel_paths_give_the_same_results():
+    """Code paths the default configuration never takes, each against the default path or the oracle:
+    (1) slot tables beyond one pass of the single-workgroup scan kernel (nx*ny*(B+1) > 131072: B >= 58 clips) go through
+        eventad_pool_finalize + eventad_pool_edges_emit; (2) fused_mark = False marks pool1's neighbour bitmap in a second
+        pass over the ELL (eventad_pool_edges_mark_ell); (3) a neighbour cap other than 16 takes the generic edge-search
+        kernel of eventad_build_ell."""
+    import torch
+    from oracle import dagr_ref, graph as G
+    from eventad_amd import synthetic, weights
+    from eventad_amd._lib import call, ptr
+    from eventad_amd.backbone import NativeBackbone
+    dev = torch.device("cuda:0")
+    sd = weights.random_graph_state()
+    # (1) 60 clips: level-0 table 56*40*61 = 136,640 slots
+    W = H = 64; B = 60; n = 300
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True))
+    (o3, o4) = dagr_ref.backbone_forward(sd, data, dagr_ref.make_config(W, H, B), data.image_feats)
+    nb = NativeBackbone(sd, W, H, dev)
+    res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    torch.cuda.synchronize()
+    assert nb.ws["levels"][0].S > 131072 and nb.check_flags() & ~1 == 0
+    n4 = int(res["out4"]["n_dev"].item())
+    assert n4 == o4.x.shape[0] and torch.equal(res["out4"]["batch"][:n4].cpu().long(), o4.batch)
+    assert torch.allclose(res["out4"]["x"][:n4].cpu(), o4.x, atol=1e-3, rtol=1e-3)
+    # (2) separate mark pass == fused mark
+    W = H = 64; B = 3; n = 3000
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True))
+    outs = []
+    for fused in (True, False):
+        nb = NativeBackbone(sd, W, H, dev)
+        nb.fused_mark = fused
+        res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+        torch.cuda.synchronize()
+        L = nb.ws["levels"][0]
+        e = int(L.e_dev.item())
+        outs.append((L.csr_src[:e].clone(), L.rowptr[: int(L.n_dev.item()) + 1].clone(),
+                     res["out4"]["x"][: int(res["out4"]["n_dev"].item())].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # (3) neighbour cap 8: generic kernel vs the oracle's builder with K = 8
+    ws, N, g = nb.ws, data.pos.shape[0], nb.geom
+    K = 8
+    ell_src = torch.empty((N, K), dtype=torch.int32, device=dev)
+    ell_step = torch.empty((N, K), dtype=torch.int16, device=dev)
+    deg = torch.empty(N, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    call("eventad_build_ell", ptr(ws["sid"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
+         N, B, W, H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ell_src), ptr(ell_step), ptr(deg), None, None, 0, 0, None, 0, 1, st)
+    edges = torch.empty((2, K * N), dtype=torch.int64, device=dev)
+    call("eventad_ell_to_edges", ptr(ell_src), ptr(deg), ptr(ws["sid"]), N, K, K * N, ptr(edges), st)
+    e = edges.cpu()
+    want = G.build_edges(data.pos, data.batch, W, H, 1000000, B, 0.01, K)
+    assert torch.equal(e[:, e[1] >= 0], want)
