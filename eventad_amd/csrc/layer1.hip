@@ -17,9 +17,9 @@
 // i < 4 and channel 16+j for i = 4), see eventad_amd/spline.py::quad_row_order.
 //
 // Mapping (64-lane waves, 16 destinations per pass, no workgroup barrier after the LUT is staged):
-//  * a wave takes groups of 64 consecutive destinations from a per-XCD work counter (dynamic: groups differ 4x in edge
-//    count), ranks the 64 by degree with ballots, and runs 4 passes of 16 destinations of (nearly) equal degree -- a wave
-//    pays for the longest row of a pass;
+//  * 64 consecutive destinations are ranked by degree with ballots and split into 4 passes of 16 destinations of (nearly)
+//    equal degree -- a wave pays for the longest row of a pass; a wave takes work items of 2 such passes from a per-XCD
+//    work counter (dynamic: items differ several times in edge count, and a wave's last item is the kernel's tail);
 //  * lane j of a destination's quad owns input channels {4j..4j+3} (+ channel 16+j when Cin = 20): a neighbour row
 //    costs one 16-byte (+ one 4-byte) load per lane, each byte of the row fetched once per quad, and only 4-5 registers;
 //    the lane keeps partial sums for all 16 outputs, reduced over the quad once per NODE with DPP adds;
@@ -34,7 +34,8 @@
 #include "common.h"
 
 #define L1_THREADS 512          // 8 waves share one LDS copy of the LUT: 2 workgroups/CU = 16 waves/CU
-#define L1_GROUP 64             // destinations per wave and work item (4 passes of 16)
+#define L1_GROUP 64             // destinations ranked together (4 passes of 16)
+#define L1_ITEM_PASSES 2        // passes per work item: a wave's last item is the kernel's tail, so items are half groups
 #define L1_MAX_WG 512
 
 // Per-lane addresses are formed as a 32-bit byte offset from a wave-uniform base pointer (arrays here are < 4 GiB), so
@@ -107,6 +108,7 @@ __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float
     nsrc = e + 4 < d ? nsrc : safe;
     int nnext = quad_bcast<0>(comp4<S>(sv2));
     nnext = S < d2 ? nnext : safe2;
+    const int src = last ? nnext : nsrc;
     // `half` (uniform): the row's last block holds at most two live slots -- slots 2 and 3 only refill their buffers
     if (S < 2 || !half) {
         if (ALL_IN_LDS) l1_fma<KL>(acc, xv[S], xe[S], wlds + cell * LS, rot);
@@ -120,7 +122,7 @@ __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float
         }
     }
     // the refill comes after the products that read the buffer, so the old row needs no copy
-    l1_load_row<CINP>(xin, last ? nnext : nsrc, j, xv[S], xe[S]);
+    l1_load_row<CINP>(xin, src, j, xv[S], xe[S]);
 }
 
 template <int CINP, bool SKIP, bool ALL_IN_LDS>
@@ -156,18 +158,20 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
     // round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so the
     // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
     const int xcd = blockIdx.x & 7;
+    constexpr int IPG = 4 / L1_ITEM_PASSES;               // work items per group
     const int ngroups = (N + L1_GROUP - 1) / L1_GROUP, g8 = (ngroups + 7) >> 3;
-    const int gbeg = xcd * g8, gend = min(gbeg + g8, ngroups);
+    const int gbeg = xcd * g8, nitems = (min(gbeg + g8, ngroups) - gbeg) * IPG;
     unsigned* ctr = work + 32 * xcd;                      // one 128-byte line per XCD: counters sharing a line serialise like one word
     auto fetch = [&]() {
         unsigned v = 0;
         if (lane == 0) v = atomicAdd(ctr, 1u);
-        return gbeg + (int)__builtin_amdgcn_readfirstlane(v);
+        return (int)__builtin_amdgcn_readfirstlane(v);
     };
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int g = fetch();
-    while (g < gend) {
-        const int gnext = fetch();                        // its round trip overlaps this group's work
+    int item = fetch();
+    while (item < nitems) {
+        const int inext = fetch();                        // its round trip overlaps this item's work
+        const int g = gbeg + item / IPG, p0 = (item % IPG) * L1_ITEM_PASSES;
         const int n0 = g * L1_GROUP;
         // rank the 64 destinations by degree (descending; ties by lane) with 17 ballots, then invert the ranking
         const int d_l = n0 + lane < N ? min(ld_off<int>(deg, 4u * (unsigned)(n0 + lane)), 16) : 0;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
         }
         const int perm = __builtin_amdgcn_ds_permute(rank << 2, lane);      // lane r <- the lane whose rank is r
         const int dperm = __builtin_amdgcn_ds_permute(rank << 2, d_l);
-        int nl = __shfl(perm, q, 64), d = __shfl(dperm, q, 64);
+        int nl = __shfl(perm, 16 * p0 + q, 64), d = __shfl(dperm, 16 * p0 + q, 64);
         int safe = min(n0 + nl, N - 1);                   // a row that exists: lanes past the end / past their degree load it
         int4 sv = ld_off<int4>(ell_src, (unsigned)safe * 64u + 16u * (unsigned)j);
         uint2 cv = ld_off<uint2>(ell_step, (unsigned)safe * 32u + 8u * (unsigned)j);
@@ -192,13 +196,14 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
             for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d ? first[u] : safe, j, xv[u], xe[u]);
         }
 #pragma unroll 1
-        for (int p = 0; p < 4; ++p) {
+        for (int p = p0; p < p0 + L1_ITEM_PASSES; ++p) {
             const int dmax = __builtin_amdgcn_readfirstlane(d);            // quad 0 of the pass has the longest row
             if (dmax == 0) break;
             const int node = n0 + nl;
             // the next pass's row (ELL slots + degree) is fetched now
-            const int r2 = 16 * (p < 3 ? p + 1 : p) + q;
-            const int nl2 = __shfl(perm, r2, 64), d2 = p < 3 ? __shfl(dperm, r2, 64) : 0;
+            const bool more = p + 1 < p0 + L1_ITEM_PASSES;
+            const int r2 = 16 * (more ? p + 1 : p) + q;
+            const int nl2 = __shfl(perm, r2, 64), d2 = more ? __shfl(dperm, r2, 64) : 0;
             const int safe2 = min(n0 + nl2, N - 1);
             const int4 sv2 = ld_off<int4>(ell_src, (unsigned)safe2 * 64u + 16u * (unsigned)j);
             const uint2 cv2 = ld_off<uint2>(ell_step, (unsigned)safe2 * 32u + 8u * (unsigned)j);
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
             }
             safe = safe2; nl = nl2; d = d2; sv = sv2; cv = cv2;
         }
-        g = gnext;
+        item = inext;
     }
 }
 
