@@ -218,3 +218,156 @@ extern "C" int eventad_l1_conv_bwd_weight(const float* x, const float* g, const 
     hipLaunchKernelGGL(k_sum_partials, dim3(evad_blocks(len, 256)), dim3(256), 0, st, partial, parts, len, dlut);
     return evad_last_error();
 }
+
+// ================================================================================ pool1 (voxel max) and the feature sampler
+// Forward (csrc/pool.hip k_pool_seg0; reference Pooling.forward with aggr = max, pooling.py:51-97, after sampling_skip,
+// net.py:200-228):  feat[slot][c] = max over the events of the voxel of  [ y2 (16) | bilinear sample of the 64-channel map ].
+// Backward of the max: the gradient of (slot, c) goes to the ONE member that attains the maximum -- what torch_scatter's
+// arg-based scatter_max backward does; among exactly equal members (the reference's choice is then whichever thread
+// wrote last) it goes to the smallest sorted position.  One wave per voxel slot walks the slot's members twice over the
+// pixel CSR, like the forward pass: first the running (max, argmax), then one row of dy2 / dsamp per member.  Every
+// event is a member of exactly one slot, so every row is written exactly once; nothing is accumulated across waves.
+__global__ __launch_bounds__(256) void k_pool_seg0_bwd(
+    const float* __restrict__ y2, const float* __restrict__ map, int map_h, int map_w, const float* __restrict__ posn_s,
+    const int* __restrict__ key_s, const int* __restrict__ node_slot, const unsigned* __restrict__ pix_start,
+    const int* __restrict__ vx_lo, const int* __restrict__ vy_lo, const int* __restrict__ ovf_list,
+    const unsigned* __restrict__ counters, int B, int W, int H, int nx, int ny, int S, const float* __restrict__ dfeat,
+    float* __restrict__ dy2, float* __restrict__ dsamp) {
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= S) return;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
+    const int plane = slot / (nx * ny), rem = slot % (nx * ny), cy = rem / nx, cx = rem % nx;
+    const int n_ovf = (int)counters[2];
+    // value of member r in this lane's channels: sampled channels 4q..4q+3 and channel q of y2 (same arithmetic as forward)
+    auto value = [&](int r, float4& v, float& yv) -> bool {
+        if (node_slot[r] != slot) return false;
+        const float px = posn_s[3 * r], py = posn_s[3 * r + 1];
+        const int b = key_s[r] / (W * H);
+        yv = y2[(size_t)r * 16 + q];
+        int x0, y0; float fx, fy;
+        evad_bilinear_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        const bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
+        const bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
+        const float* p00 = map + (((size_t)b * map_h + y0) * map_w + x0) * 64 + 4 * q;
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto add = [&](bool ok, const float* p, float w) {
+            if (!ok) return;
+            const float4 c = *(const float4*)p;
+            v.x += c.x * w; v.y += c.y * w; v.z += c.z * w; v.w += c.w * w;
+        };
+        add(vx0 && vy0, p00, w00); add(vx1 && vy0, p00 + 64, w01);
+        add(vx0 && vy1, p00 + (size_t)map_w * 64, w10); add(vx1 && vy1, p00 + (size_t)map_w * 64 + 64, w11);
+        return true;
+    };
+    auto for_members = [&](auto&& fn) {                      // this group's share of the slot's members
+        if (plane < B) {
+            const int xa = vx_lo[cx], xb = vx_lo[cx + 1], ya = vy_lo[cy], yb = vy_lo[cy + 1];
+            for (int yy = ya; yy < yb; ++yy) {
+                const int base = W * (yy + H * plane);
+                const int ra = (int)pix_start[base + xa], rb = (int)pix_start[base + xb];
+                for (int r = ra + grp; r < rb; r += 4) fn(r);
+            }
+        }
+        for (int i = grp; i < n_ovf; i += 4) fn(ovf_list[i]);
+    };
+    const float NEG = -__builtin_inff();
+    float mv[5] = {NEG, NEG, NEG, NEG, NEG};                 // running max of the 4 sampled channels and of y2's channel
+    int am[5] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    auto take = [&](int c, float v, int r) { if (v > mv[c] || (v == mv[c] && r < am[c])) { mv[c] = v; am[c] = r; } };
+    for_members([&](int r) {
+        float4 v; float yv;
+        if (!value(r, v, yv)) return;
+        take(0, v.x, r); take(1, v.y, r); take(2, v.z, r); take(3, v.w, r); take(4, yv, r);
+    });
+#pragma unroll
+    for (int d = 16; d <= 32; d <<= 1)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { const float ov = __shfl_xor(mv[c], d, 64); const int oa = __shfl_xor(am[c], d, 64); take(c, ov, oa); }
+    const float* gs = dfeat + (size_t)slot * 80;
+    const float gy = gs[q];
+    const float4 g4 = *(const float4*)(gs + 16 + 4 * q);
+    for_members([&](int r) {
+        if (node_slot[r] != slot) return;
+        dy2[(size_t)r * 16 + q] = am[4] == r ? gy : 0.f;
+        *(float4*)(dsamp + (size_t)r * 64 + 4 * q) = make_float4(am[0] == r ? g4.x : 0.f, am[1] == r ? g4.y : 0.f,
+                                                                 am[2] == r ? g4.z : 0.f, am[3] == r ? g4.w : 0.f);
+    });
+}
+
+/* dfeat f32[S,80] = dL/d(slot feature table of pool1), S = nx*ny*(B+1); the forward inputs as eventad_pool_seg0 takes
+ * them.  Out: dy2 f32[N,16], dsamp f32[N,64] (pixel-sorted numbering); every row of both is written. */
+extern "C" int eventad_pool_seg0_bwd(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
+                                     const int32_t* key_s, const int32_t* node_slot, const uint32_t* pix_start,
+                                     const int32_t* vx_lo, const int32_t* vy_lo, const int32_t* ovf_list, const uint32_t* counters,
+                                     int N, int B, int W, int H, int nx, int ny, const float* dfeat, float* dy2, float* dsamp,
+                                     void* stream) {
+    if (!y2 || !map_nhwc || !posn_s || !key_s || !node_slot || !pix_start || !vx_lo || !vy_lo || !ovf_list || !counters ||
+        !dfeat || !dy2 || !dsamp || N < 0 || B <= 0 || nx <= 0 || ny <= 0 || map_h <= 0 || map_w <= 0)
+        return EVAD_ERR_ARG;
+    if (N == 0) return EVAD_OK;
+    const int S = nx * ny * (B + 1);
+    hipLaunchKernelGGL(k_pool_seg0_bwd, dim3(evad_blocks(S, 4)), dim3(256), 0, (hipStream_t)stream, y2, map_nhwc, map_h, map_w,
+                       posn_s, key_s, node_slot, pix_start, vx_lo, vy_lo, ovf_list, counters, B, W, H, nx, ny, S, dfeat, dy2, dsamp);
+    return evad_last_error();
+}
+
+// Transpose of the bilinear sampler (reference: autograd through F.grid_sample in net.py:211-228):
+//     dmap[b][ym][xm][c] = sum over events of clip b with a bilinear corner at (xm, ym) of  weight * g[event][c].
+// Gather form, no float atomics: one wave per map pixel.  The events that can touch the pixel lie in a small rectangle of
+// sensor pixels, i.e. in one contiguous range of the pixel-sorted array per sensor row; the rectangle is taken one pixel
+// too large on every side and each event's corner weights are recomputed exactly as the forward pass does, so the
+// membership test is the forward arithmetic itself.  4 groups of 16 lanes take every 4th event of a row range and are
+// merged by a fixed tree: the sum order is the same in every run.
+template <int CPL>      // channels per lane: the map has 16 * CPL channels
+__global__ __launch_bounds__(256) void k_sample_bwd(const float* __restrict__ g, int ldg, const float* __restrict__ posn_s,
+                                                    const unsigned* __restrict__ pix_start, int B, int W, int H, int map_h,
+                                                    int map_w, float* __restrict__ dmap) {
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long long)B * map_h * map_w) return;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
+    const int xm = (int)(wv % map_w), ym = (int)((wv / map_w) % map_h), b = (int)(wv / ((long long)map_w * map_h));
+    const float sx = map_w > 1 ? (float)(W - 1) / (float)(map_w - 1) : (float)W;
+    const float sy = map_h > 1 ? (float)(H - 1) / (float)(map_h - 1) : (float)H;
+    const int xlo = max(0, (int)floorf((float)(xm - 1) * sx) - 1), xhi = min(W - 1, (int)ceilf((float)(xm + 1) * sx) + 1);
+    const int ylo = max(0, (int)floorf((float)(ym - 1) * sy) - 1), yhi = min(H - 1, (int)ceilf((float)(ym + 1) * sy) + 1);
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    for (int yy = ylo; yy <= yhi; ++yy) {
+        const int base = W * (yy + H * b);
+        const int ra = (int)pix_start[base + xlo], rb = (int)pix_start[base + xhi + 1];
+        for (int r = ra + grp; r < rb; r += 4) {
+            int x0, y0; float fx, fy;
+            evad_bilinear_setup(posn_s[3 * r], posn_s[3 * r + 1], (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+            const bool left = x0 == xm, right = x0 + 1 == xm, top = y0 == ym, bottom = y0 + 1 == ym;
+            if (!(left || right) || !(top || bottom)) continue;
+            const float w = (left ? 1.f - fx : fx) * (top ? 1.f - fy : fy);       // the forward pass's w00 / w01 / w10 / w11
+            const float* gr = g + (size_t)r * ldg + q * CPL;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] += gr[c] * w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { acc[c] += __shfl_xor(acc[c], 16, 64); acc[c] += __shfl_xor(acc[c], 32, 64); }
+    if (grp == 0) {
+        float* o = dmap + (size_t)wv * (16 * CPL) + q * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) o[c] = acc[c];
+    }
+}
+
+/* g: f32 rows of `ldg` floats in pixel-sorted numbering, the gradient of the sampled channels starting at g[r*ldg]
+ * (pass dx0s + 1 with ldg = 20 for the 16-channel map of Layer 1's input, dsamp with ldg = 64 for pool1's 64-channel map).
+ * dmap f32[B, map_h, map_w, C] (NHWC like the forward input), C = 16 or 64; every element is written. */
+extern "C" int eventad_sample_bwd(const float* g, int ldg, int C, const float* posn_s, const uint32_t* pix_start, int N, int B,
+                                  int W, int H, int map_h, int map_w, float* dmap, void* stream) {
+    if (!g || !posn_s || !pix_start || !dmap || N < 0 || B <= 0 || W <= 0 || H <= 0 || map_h <= 0 || map_w <= 0 || ldg < C ||
+        (C != 16 && C != 64))
+        return EVAD_ERR_ARG;
+    const long long waves = (long long)B * map_h * map_w;
+    const dim3 grid(evad_blocks(waves, 4));
+    if (C == 16) hipLaunchKernelGGL(k_sample_bwd<1>, grid, dim3(256), 0, (hipStream_t)stream, g, ldg, posn_s, pix_start, B, W, H, map_h, map_w, dmap);
+    else         hipLaunchKernelGGL(k_sample_bwd<4>, grid, dim3(256), 0, (hipStream_t)stream, g, ldg, posn_s, pix_start, B, W, H, map_h, map_w, dmap);
+    return evad_last_error();
+}

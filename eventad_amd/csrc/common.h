@@ -54,6 +54,19 @@ __device__ __forceinline__ float evad_ord2f(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// Bilinear sampling set-up of F.grid_sample(align_corners=True) as the reference calls it (net.py:211-228): normalised
+// event position -> top-left map pixel + fractions, every step rounded like the reference's separate torch ops.
+__device__ __forceinline__ void evad_bilinear_setup(float px_norm, float py_norm, float Wf, float Hf, int w_in, int h_in,
+                                               int* x0, int* y0, float* fx, float* fy) {
+    float x = __fmul_rn(px_norm, Wf), y = __fmul_rn(py_norm, Hf);
+    float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, x), Wf - 1.f), 1.f);
+    float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, y), Hf - 1.f), 1.f);
+    float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.f), 2.f), (float)(w_in - 1));
+    float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yn, 1.f), 2.f), (float)(h_in - 1));
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    *x0 = (int)fx0; *y0 = (int)fy0; *fx = ix - fx0; *fy = iy - fy0;
+}
+
 // Pooled-edge dedup (pool.hip): bit index of a source slot relative to its destination slot in the
 // destination's 5x5x3 neighbour-window bitmap: ((dp+1)*5 + (dy+2))*5 + (dx+2).
 __device__ __forceinline__ void evad_mark_edge(int ss, int sd, int nx, int ny, unsigned* __restrict__ bitmap, unsigned* flags) {

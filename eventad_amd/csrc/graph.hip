@@ -315,17 +315,6 @@ __global__ void k_scatter_events(const int* __restrict__ key, const unsigned* __
 //   x0s[r] = [polarity, 16 bilinear samples of CNN map 0, pos_x, pos_y, 0]   (reference net.py:116,122-123)
 // The sampler restates F.grid_sample(align_corners=True, zeros padding) as called by
 // net.py:211-228; the batch coordinate is integral so the trilinear blend reduces to bilinear.
-__device__ __forceinline__ void bilinear_setup(float px_norm, float py_norm, float Wf, float Hf, int w_in, int h_in,
-                                               int* x0, int* y0, float* fx, float* fy) {
-    float x = __fmul_rn(px_norm, Wf), y = __fmul_rn(py_norm, Hf);
-    float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, x), Wf - 1.f), 1.f);
-    float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, y), Hf - 1.f), 1.f);
-    float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.f), 2.f), (float)(w_in - 1));
-    float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yn, 1.f), 2.f), (float)(h_in - 1));
-    float fx0 = floorf(ix), fy0 = floorf(iy);
-    *x0 = (int)fx0; *y0 = (int)fy0; *fx = ix - fx0; *fy = iy - fy0;
-}
-
 __global__ void k_gather_sorted(const int* __restrict__ sid_tmp, const unsigned* __restrict__ start, int* __restrict__ sid,
                                 const int* __restrict__ key, const int* __restrict__ tq,
                                 const float* __restrict__ pos, const float* __restrict__ pol,
@@ -371,7 +360,7 @@ __global__ void k_gather_sorted(const int* __restrict__ sid_tmp, const unsigned*
         if ((int)sl != tab) ovf_list[atomicAdd(counters + 2, 1u)] = r;
     }
     int x0, y0; float fx, fy;
-    bilinear_setup(px, py, (float)W, (float)H, w_in, h_in, &x0, &y0, &fx, &fy);
+    evad_bilinear_setup(px, py, (float)W, (float)H, w_in, h_in, &x0, &y0, &fx, &fy);
     float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
     bool vx0 = x0 >= 0 && x0 < w_in, vx1 = x0 + 1 >= 0 && x0 + 1 < w_in;
     bool vy0 = y0 >= 0 && y0 < h_in, vy1 = y0 + 1 >= 0 && y0 + 1 < h_in;
@@ -547,8 +536,16 @@ __global__ __launch_bounds__(256) void k_build_ell(const int* __restrict__ sid, 
 // issues ~620 vector-memory instructions per wave, a third of them 2- and 4-byte scattered stores; on
 // CDNA a load's s_waitcnt also waits for every older store (vmcnt counts both), so stores inside the
 // dependent chain lengthen every later round trip.
-template <bool MARK>
-__global__ __launch_bounds__(256) void k_build_ell_reg(const int2* __restrict__ ev2,
+// (c) Lane assignment: a wave pays for the longest walk of its 64 lanes, and the length of a walk depends mostly on
+// how EARLY the event is in its clip (an early event finds few older events per pixel and walks far; with dense
+// input every 64 consecutive pixel-sorted events hold one such event).  A workgroup therefore takes a tile of
+// 1024 consecutive pixel-sorted events and deals them to its 16 waves by id rank (64 LDS buckets over the tile's
+// id range): the long walks of a tile share a few waves and the other waves finish early.  Which lane computes
+// which row changes nothing in the rows themselves.  The price is that a wave's loads touch more cache lines, so
+// the host asks for it (BY_RANK) only for dense input (C5: 23.2 vs 28.5 ms; C4, 0.5 events per pixel: 7.3 vs 6.5 ms).
+#define ELL_TILE 1024
+template <bool MARK, bool BY_RANK>
+__global__ __launch_bounds__(ELL_TILE) void k_build_ell_reg(const int2* __restrict__ ev2,
                                                        const int* __restrict__ key_s, const unsigned* __restrict__ start,
                                                        const unsigned* flags_in, int N, int W, int H, int steps, int Q,
                                                        int dt_max, int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
@@ -556,7 +553,40 @@ __global__ __launch_bounds__(256) void k_build_ell_reg(const int2* __restrict__ 
                                                        const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
                                                        unsigned* flags) {
     constexpr int MAXNB = 16;
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_perm[ELL_TILE];
+    __shared__ int s_cnt[64];
+    __shared__ int s_mm[2];
+    const int tid = threadIdx.x, r0 = blockIdx.x * ELL_TILE + tid;
+    int r = r0;
+    if (BY_RANK) {
+    if (tid < 64) s_cnt[tid] = 0;
+    if (tid == 0) { s_mm[0] = 0x7fffffff; s_mm[1] = 0; }
+    __syncthreads();
+    const int id0 = r0 < N ? ev2[r0].x : -1;
+    {
+        int mn = id0 < 0 ? 0x7fffffff : id0, mx = id0 < 0 ? 0 : id0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+        if ((tid & 63) == 0) { atomicMin(&s_mm[0], mn); atomicMax(&s_mm[1], mx); }
+    }
+    __syncthreads();
+    const int lo_id = s_mm[0];
+    const float scale = 64.f / (float)(s_mm[1] - lo_id + 1);
+    const int bucket = id0 < 0 ? 63 : min(63, (int)((float)(id0 - lo_id) * scale));
+    const int rank_in_bucket = atomicAdd(&s_cnt[bucket], 1);
+    __syncthreads();
+    if (tid < 64) {                                              // exclusive scan of the 64 bucket counts (wave 0)
+        const int c = s_cnt[tid];
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
+        s_cnt[tid] = incl - c;
+    }
+    __syncthreads();
+    s_perm[s_cnt[bucket] + rank_in_bucket] = r0;
+    __syncthreads();
+    r = s_perm[tid];
+    }
     if (r >= N) return;
     const bool monotone = !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE);
     const int k = key_s[r];
@@ -780,12 +810,13 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
 #undef EVAD_RS
     } else if (fast) {
-        if (bitmap)
-            hipLaunchKernelGGL(k_build_ell_reg<true>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
-                               counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
-        else
-            hipLaunchKernelGGL(k_build_ell_reg<false>, grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start,
-                               counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters);
+        const dim3 tgrid(evad_blocks(N, ELL_TILE));
+        const bool by_rank = (double)N >= 2.0 * (double)B * W * H;          // >= 2 events per pixel on average
+#define EVAD_REG(MK, BR) hipLaunchKernelGGL((k_build_ell_reg<MK, BR>), tgrid, dim3(ELL_TILE), 0, st, (const int2*)ev2, key_s, pix_start, \
+                               counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters)
+        if (bitmap) { if (by_rank) EVAD_REG(true, true); else EVAD_REG(true, false); }
+        else        { if (by_rank) EVAD_REG(false, true); else EVAD_REG(false, false); }
+#undef EVAD_REG
     } else {                                                 // any neighbour cap / radius: the reference-style walk
         if (bitmap) return EVAD_ERR_ARG;                     // (mark with eventad_pool_edges_mark_ell afterwards)
         hipLaunchKernelGGL(k_build_ell, grid, dim3(256), 0, st, sid, ts_s, key_s, pix_start, g_spiral_dev, counters, N, W, H,

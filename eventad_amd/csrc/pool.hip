@@ -18,17 +18,6 @@
 //                  ascending source id = the reference's unique(dim=-1) order within a destination.
 #include "common.h"
 
-__device__ __forceinline__ void bilin_setup(float px_norm, float py_norm, float Wf, float Hf, int w_in, int h_in,
-                                            int* x0, int* y0, float* fx, float* fy) {
-    float x = __fmul_rn(px_norm, Wf), y = __fmul_rn(py_norm, Hf);
-    float xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, x), Wf - 1.f), 1.f);
-    float yn = __fsub_rn(__fdiv_rn(__fmul_rn(2.f, y), Hf - 1.f), 1.f);
-    float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.f), 2.f), (float)(w_in - 1));
-    float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yn, 1.f), 2.f), (float)(h_in - 1));
-    float fx0 = floorf(ix), fy0 = floorf(iy);
-    *x0 = (int)fx0; *y0 = (int)fy0; *fx = ix - fx0; *fy = iy - fy0;
-}
-
 // grid_cluster (torch_cluster): c_d = (int64)((pos_d - 0) / size_d); slot = cx + nx*cy + nx*ny*(clip + t-cell), clamped into the table
 __device__ __forceinline__ int pool_slot_of(float px, float py, float pt, int b, float vsx, float vsy, int nx, int ny, int S, bool* bad) {
     int cx = (int)__fdiv_rn(px, vsx), cy = (int)__fdiv_rn(py, vsy), ct = (int)pt;
@@ -67,7 +56,7 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
     }
     if (Cm > 0) {
         int x0, y0; float fx, fy;
-        bilin_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+        evad_bilinear_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
         float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
         bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
         bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
@@ -130,7 +119,7 @@ __global__ __launch_bounds__(256) void k_pool_mean_gather(const float* __restric
             if (c < Ca) v = xa[(size_t)i * lda + c];
             else {
                 int x0, y0; float fx, fy;
-                bilin_setup(npos[3 * i], npos[3 * i + 1], (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+                evad_bilinear_setup(npos[3 * i], npos[3 * i + 1], (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
                 float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
                 bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
                 bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
@@ -222,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
         if (ns != slot) return;
         int b = k / (W * H);
         int x0, y0; float fx, fy;
-        bilin_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+        evad_bilinear_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
         float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
         bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
         bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;

@@ -1,5 +1,5 @@
-"""Backward of the event-level LUT spline convolution through the native kernels (csrc/bwd.hip) -- the message-passing
-gradient a fine-tuning of the DAGR backbone needs.  The reference gets it from autograd over MySplineConv's gather +
+"""Backward of the event-level stage through the native kernels (csrc/bwd.hip) -- LUT spline convolution, pool1's voxel
+max and the CNN-feature sampler: the gradients a fine-tuning of the DAGR backbone needs.  The reference gets it from autograd over MySplineConv's gather +
 scatter-add (src/dagr/model/layers/spline_conv.py:39-78); EventAD itself freezes the backbone (models/EventAD.py:148-150),
 so nothing here runs in its training step.
 
@@ -62,3 +62,39 @@ class EventConvBackward:
              ptr(dlut), N, steps, cin_pad, st)
         dw, dr = torch.autograd.grad(full, (w_cpu, r_cpu), dlut.cpu())          # the LUT is linear in (weight, root)
         return dx, dw, dr
+
+
+class EventPoolBackward:
+    """Gradients of pool1 (voxel max over [layer-1 output | 64 sampled CNN channels], reference pooling.py:51-97 after
+    net.py:200-228) and of the bilinear samplers, on the workspace a NativeBackbone.front() pass left behind."""
+
+    def __init__(self, backbone):
+        self.nb = backbone
+
+    def pool1(self, N, B, dfeat, y2=None, fmap=None):
+        """dfeat f32[S,80] = dL/d(slot feature table of level 0).  y2 / fmap default to the forward pass's own layer-1
+        output and 64-channel NHWC map.  -> (dy2 f32[N,16], dsamp f32[N,64]) in pixel-sorted numbering."""
+        nb, ws, g = self.nb, self.nb.ws, self.nb.geom
+        L = ws["levels"][0]
+        y2 = ws["y2"] if y2 is None else y2.contiguous()
+        fmap = fmap.contiguous()
+        assert tuple(dfeat.shape) == (L.S, 80) and fmap.shape[0] == B and fmap.shape[3] == 64
+        dfeat = dfeat.contiguous().float()
+        dy2 = torch.empty((N, 16), device=dfeat.device)
+        dsamp = torch.empty((N, 64), device=dfeat.device)
+        call("eventad_pool_seg0_bwd", ptr(y2), ptr(fmap), fmap.shape[1], fmap.shape[2], ptr(ws["posn_s"]), ptr(ws["key_s"]),
+             ptr(ws["node_slot0"]), ptr(ws["pix_start"]), ptr(nb.vox_tabs[2]), ptr(nb.vox_tabs[3]), ptr(ws["ovf_list"]),
+             ptr(ws["counters"]), N, B, g.W, g.H, L.nx, L.ny, ptr(dfeat), ptr(dy2), ptr(dsamp),
+             torch.cuda.current_stream().cuda_stream)
+        return dy2, dsamp
+
+    def sampler(self, N, B, grad_rows, channels, map_h, map_w, column=0):
+        """grad_rows f32[N, ld]: per-event gradient rows (pixel-sorted numbering) holding the sampled channels at
+        [column, column + channels).  -> dL/d(feature map) f32[B, map_h, map_w, channels] (NHWC)."""
+        ws, g = self.nb.ws, self.nb.geom
+        grad_rows = grad_rows.contiguous().float()
+        assert grad_rows.shape[0] >= N and grad_rows.shape[1] >= column + channels
+        dmap = torch.empty((B, map_h, map_w, channels), device=grad_rows.device)
+        call("eventad_sample_bwd", grad_rows.data_ptr() + 4 * column, grad_rows.shape[1], channels, ptr(ws["posn_s"]),
+             ptr(ws["pix_start"]), N, B, g.W, g.H, map_h, map_w, ptr(dmap), torch.cuda.current_stream().cuda_stream)
+        return dmap

@@ -273,7 +273,7 @@ int eventad_masked_inplace_bn(const int64_t* indices, const float* x, float* x_o
 int eventad_masked_lin(const int64_t* indices, const float* x_in, float* x_out, const float* weight, const float* bias,
                        int K, int Cin, int Cout, int add, void* stream);
 
-/* ---- (I) backward of the event-level LUT spline convolution (fine-tuning the backbone) ------------------------- */
+/* ---- (I) backward of the event-level stage: LUT spline convolution, pool1, feature sampler (fine-tuning the backbone) */
 /* The reference obtains these from autograd over MySplineConv's gather + scatter-add (spline_conv.py:39-78).  All of
  * them are free of float atomics: bitwise reproducible.
  * eventad_ell_transpose: out-edges per source from the ELL adjacency.  out_start u32[N+1], out_edge i32[16N] (key =
@@ -292,6 +292,21 @@ int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_start, const in
 int eventad_l1_conv_bwd_weight_parts(int N);
 int eventad_l1_conv_bwd_weight(const float* x, const float* g, const int32_t* ell_src, const uint16_t* ell_step,
                                const int32_t* deg, float* partial, float* dlut, int N, int steps, int cin_pad, void* stream);
+/* Backward of pool1's voxel max (Pooling.forward with aggr = max, pooling.py:51-97; the reference's gradient is
+ * torch_scatter's arg-based scatter_max backward).  Inputs as eventad_pool_seg0 plus dfeat f32[S,80] = dL/d(slot feature
+ * table), S = nx*ny*(B+1).  Out: dy2 f32[N,16] (layer-1 output channels) and dsamp f32[N,64] (sampled map channels), one
+ * row per event, pixel-sorted numbering; the gradient of (slot, channel) goes to the member that attains the maximum
+ * (smallest sorted position among exactly equal members). */
+int eventad_pool_seg0_bwd(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
+                          const int32_t* key_s, const int32_t* node_slot, const uint32_t* pix_start,
+                          const int32_t* vx_lo, const int32_t* vy_lo, const int32_t* ovf_list, const uint32_t* counters,
+                          int N, int B, int W, int H, int nx, int ny, const float* dfeat, float* dy2, float* dsamp,
+                          void* stream);
+/* Transpose of the bilinear feature sampler (autograd through F.grid_sample, net.py:211-228): dmap f32[B,map_h,map_w,C]
+ * (NHWC, C = 16 or 64) from g = rows of `ldg` floats per event (pixel-sorted numbering) whose first C entries are the
+ * gradient of the sampled channels.  Gather per map pixel over the pixel CSR, fixed summation order. */
+int eventad_sample_bwd(const float* g, int ldg, int C, const float* posn_s, const uint32_t* pix_start, int N, int B,
+                       int W, int H, int map_h, int map_w, float* dmap, void* stream);
 
 #ifdef __cplusplus
 }
