@@ -48,7 +48,9 @@ class NativeBackbone:
         # windows, the register-row spiral walk (0, early exit after 16 neighbours) for dense ones
         v = os.environ.get("EVENTAD_ELL_VARIANT")
         self.ell_variant = int(v) if v else None
-        self.fused_mark = True         # pool1 edge bitmap filled by the edge search itself: 172 us vs 134 + 98 us separate (C2)
+        # who fills pool1's neighbour bitmap: True = the wave-per-voxel pooling kernel (no atomics; default),
+        # "edge_search" = the edge search while the ELL row is in registers (atomics), False = a pass of its own over the ELL
+        self.fused_mark = True
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
 
@@ -258,7 +260,7 @@ class NativeBackbone:
              ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["counters"]),
              N, B, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q, ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
              ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), g.grid[0][0], g.grid[0][1],
-             ptr(ws["levels"][0].bitmap) if self.fused_mark else None, sw, 1, st)
+             ptr(ws["levels"][0].bitmap) if self.fused_mark == "edge_search" else None, sw, 1, st)
         self._c("eventad_l1_conv1", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
              ptr(w["shift1"]), ptr(ws["y1"]), ptr(ws["l1_work"][:256]), N, g.steps, K, st)
         self._c("eventad_l1_conv2", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
@@ -269,7 +271,8 @@ class NativeBackbone:
         self._c("eventad_pool_seg0", ptr(ws["y2"]), ptr(fmap), fmap.shape[1], fmap.shape[2], ptr(ws["posn_s"]),
                 ptr(ws["key_s"]), ptr(ws["sid"]), ptr(ws["node_slot0"]), ptr(ws["pix_start"]), ptr(self.vox_tabs[2]),
                 ptr(self.vox_tabs[3]), ptr(ws["ovf_list"]), ptr(ws["counters"]), N, B, g.W, g.H, L.nx, L.ny,
-                ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), st)
+                ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["ell_src"]), ptr(ws["deg"]),
+                ptr(ws["node_vox0"]), ptr(L.bitmap) if self.fused_mark is True else None, st)
         small = L.S <= 131072                               # both scans of the level fit the single-workgroup kernel
         if not self.fused_mark:
             self._c("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,

@@ -184,16 +184,23 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
 
 
 // --------------------------------------------------------------------------- level 0 without atomics
-// One wave per voxel slot; 4 groups of 16 lanes process 4 member events at a time (lane q of a group:
-// sampled channels 4q..4q+3 as one float4 per bilinear corner + channel q of the layer-1 output), then
-// a fixed shuffle tree merges the groups.  Max is exact and order independent; integer pixel sums too.
+// One wave per voxel slot, two phases per chunk of up to 64 candidate events:
+//  (1) lane l takes candidate l of the slot's pixel rows (a voxel row is one contiguous range of the pixel-sorted
+//      array; the lanes enumerate up to 8 row ranges at once through their prefix sums): it loads the candidate's
+//      slot, position, pixel key and id, keeps the integer statistics, and computes the bilinear set-up ONCE per event;
+//  (2) 4 groups of 16 lanes then walk the chunk 4 members at a time, taking a member's set-up from its lane by
+//      ds_bpermute: lane q of a group reads sampled channels 4q..4q+3 (one float4 per bilinear corner) and channel q
+//      of the layer-1 output.  All loads of an iteration are unconditional (a corner outside the map reads a valid
+//      address with weight 0; adding c * 0 leaves the sum unchanged), so iterations overlap.
+// A fixed shuffle tree merges the groups.  Max is exact and order independent; integer pixel sums too.
 __global__ __launch_bounds__(256) void k_pool_seg0(
     const float* __restrict__ y2, const float* __restrict__ map, int map_h, int map_w, const float* __restrict__ posn_s,
     const int* __restrict__ key_s, const int* __restrict__ sid, const int* __restrict__ node_slot,
     const unsigned* __restrict__ pix_start, const int* __restrict__ vx_lo, const int* __restrict__ vy_lo,
-    const int* __restrict__ ovf_list, const unsigned* __restrict__ counters, int B, int W, int H, int nx, int ny, int S,
+    const int* __restrict__ ovf_list, unsigned* __restrict__ counters, int B, int W, int H, int nx, int ny, int S,
     float* __restrict__ feat, unsigned long long* __restrict__ sums, unsigned long long* __restrict__ tsum, unsigned* __restrict__ cnt,
-    int* __restrict__ maxidx) {
+    int* __restrict__ maxidx, const int* __restrict__ ell_src, const int* __restrict__ deg, const int* __restrict__ node_vox,
+    unsigned* __restrict__ bitmap) {
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= S) return;
     const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
@@ -201,82 +208,142 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     const float NEG = -__builtin_inff();
     float4 mx = make_float4(NEG, NEG, NEG, NEG);
     float my = NEG;
-    unsigned n = 0; unsigned long long sx = 0, sy = 0, ts = 0; int mi = 0;         // mi = max member id + 1
-    auto member = [&](int r) {
-        // all index / position loads of the member go out together; the slot test only gates the map reads
-        const int ns = node_slot[r];
-        const float px = posn_s[3 * r], py = posn_s[3 * r + 1], pt = posn_s[3 * r + 2];
-        const int k = key_s[r], id = sid[r];
-        const float yv = y2[(size_t)r * 16 + q];
-        if (ns != slot) return;
-        int b = k / (W * H);
-        int x0, y0; float fx, fy;
-        evad_bilinear_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
-        float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
-        bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
-        bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
-        const float* p00 = map + (((size_t)b * map_h + y0) * map_w + x0) * 64 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto add = [&](bool ok, const float* p, float w) {
-            if (!ok) return;
-            float4 c = *(const float4*)p;
-            v.x += c.x * w; v.y += c.y * w; v.z += c.z * w; v.w += c.w * w;
-        };
-        add(vx0 && vy0, p00, w00); add(vx1 && vy0, p00 + 64, w01);
-        add(vx0 && vy1, p00 + (size_t)map_w * 64, w10); add(vx1 && vy1, p00 + (size_t)map_w * 64 + 64, w11);
-        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-        my = fmaxf(my, yv);
-        if (q == 0) { ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H);
-                      ts += (unsigned long long)llrintf(pt * 1099511627776.f); mi = max(mi, id + 1); }
+    unsigned n = 0, sx = 0, sy = 0; unsigned long long ts = 0; int mi = 0;         // per-lane partial statistics; mi = max member id + 1
+    // pool1's neighbour bitmap (which voxels of the 5x5x3 window around this one send it an edge): this wave owns the
+    // slot's three words, so the marks of all its members' in-edges are OR-ed in registers and stored once -- no atomics,
+    // no pre-zeroed table.  Lane q of a group looks at ELL slot q of the group's member.
+    unsigned bm0 = 0, bm1 = 0, bm2 = 0; bool bad = false;
+    // one chunk: candidate r of this lane (have = the lane holds a candidate), count = candidates in the chunk
+    auto chunk = [&](int r, bool have, int count) {
+        int off = 0, cmask = 0; float fx = 0.f, fy = 0.f;
+        if (have) {
+            const int ns = node_slot[r];
+            const float px = posn_s[3 * r], py = posn_s[3 * r + 1], pt = posn_s[3 * r + 2];
+            const int k = key_s[r], id = sid[r];
+            if (ns == slot) {
+                ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H);
+                ts += (unsigned long long)llrintf(pt * 1099511627776.f); mi = max(mi, id + 1);
+                const int b = k / (W * H);
+                int x0, y0;
+                evad_bilinear_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+                const bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
+                const bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
+                cmask = 16 | (vx0 && vy0 ? 1 : 0) | (vx1 && vy0 ? 2 : 0) | (vx0 && vy1 ? 4 : 0) | (vx1 && vy1 ? 8 : 0);
+                off = ((b * map_h + y0) * map_w + x0) * 64;   // float offset of the top-left corner (only used where valid)
+            }
+        }
+        const int iters = (count + 3) >> 2;
+        for (int it = 0; it < iters; ++it) {
+            const int m = it * 4 + grp;                      // < 64 whenever it < iters
+            const int m_r = __shfl(r, m, 64), m_mask = __shfl(cmask, m, 64), m_off = __shfl(off, m, 64);
+            const float m_fx = __shfl(fx, m, 64), m_fy = __shfl(fy, m, 64);
+            const bool ok = (m_mask & 16) != 0;
+            const int rr = ok ? m_r : 0;
+            const float* p00 = map + (ok ? m_off : 0) + 4 * q;
+            const float4 c00 = *(const float4*)((m_mask & 1) ? p00 : map);
+            const float4 c01 = *(const float4*)((m_mask & 2) ? p00 + 64 : map);
+            const float4 c10 = *(const float4*)((m_mask & 4) ? p00 + (size_t)map_w * 64 : map);
+            const float4 c11 = *(const float4*)((m_mask & 8) ? p00 + (size_t)map_w * 64 + 64 : map);
+            const float yv = y2[(size_t)rr * 16 + q];
+            int e_src = 0, e_deg = 0;
+            if (bitmap) { e_src = ell_src[(size_t)rr * 16 + q]; e_deg = deg[rr]; }
+            const float w00 = (m_mask & 1) ? (1.f - m_fx) * (1.f - m_fy) : 0.f, w01 = (m_mask & 2) ? m_fx * (1.f - m_fy) : 0.f;
+            const float w10 = (m_mask & 4) ? (1.f - m_fx) * m_fy : 0.f, w11 = (m_mask & 8) ? m_fx * m_fy : 0.f;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x += c00.x * w00; v.y += c00.y * w00; v.z += c00.z * w00; v.w += c00.w * w00;
+            v.x += c01.x * w01; v.y += c01.y * w01; v.z += c01.z * w01; v.w += c01.w * w01;
+            v.x += c10.x * w10; v.y += c10.y * w10; v.z += c10.z * w10; v.w += c10.w * w10;
+            v.x += c11.x * w11; v.y += c11.y * w11; v.z += c11.z * w11; v.w += c11.w * w11;
+            if (ok) {
+                mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+                my = fmaxf(my, yv);
+            }
+            if (bitmap && ok && q >= 1 && q < e_deg) {
+                const int vs = node_vox[e_src];
+                const int dx = (vs & 255) - cx, dy = ((vs >> 8) & 255) - cy, dp = (vs >> 16) - plane;
+                if (dx | dy | dp) {                          // an edge inside one voxel is a self loop after pooling: dropped
+                    if (dx < -2 || dx > 2 || dy < -2 || dy > 2 || dp < -1 || dp > 1) bad = true;
+                    else {
+                        const int bit = ((dp + 1) * 5 + (dy + 2)) * 5 + (dx + 2);
+                        const unsigned mk = 1u << (bit & 31);
+                        if (bit < 32) bm0 |= mk; else if (bit < 64) bm1 |= mk; else bm2 |= mk;
+                    }
+                }
+            }
+        }
     };
     if (plane < B) {
         const int x0 = vx_lo[cx], x1 = vx_lo[cx + 1], y0 = vy_lo[cy], y1 = vy_lo[cy + 1];
         for (int yb = y0; yb < y1; yb += 8) {               // the CSR bounds of 8 pixel rows load together
-            int ra[8], rb[8];
+            int ra[8], pre[9];
+            pre[0] = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                ra[i] = 0; rb[i] = 0;
+                int a = 0, b = 0;
                 if (yb + i < y1) {
                     const int base = W * (yb + i + H * plane);
-                    ra[i] = (int)pix_start[base + x0]; rb[i] = (int)pix_start[base + x1];   // a voxel row is contiguous in sorted order
+                    a = (int)pix_start[base + x0]; b = (int)pix_start[base + x1];   // a voxel row is contiguous in sorted order
                 }
+                ra[i] = a; pre[i + 1] = b - a;
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                for (int r = ra[i] + grp; r < rb[i]; r += 4) member(r);
+            for (int i = 0; i < 8; ++i) pre[i + 1] += pre[i];
+            const int total = pre[8];
+            for (int c0 = 0; c0 < total; c0 += 64) {
+                const int idx = c0 + lane;
+                int o = ra[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) o = idx >= pre[i] ? ra[i] - pre[i] : o;
+                chunk(o + idx, idx < total, min(64, total - c0));
+            }
         }
     }
     const int n_ovf = (int)counters[2];
-    for (int i = grp; i < n_ovf; i += 4) member(ovf_list[i]);
+    for (int c0 = 0; c0 < n_ovf; c0 += 64) {
+        const bool have = c0 + lane < n_ovf;
+        chunk(have ? ovf_list[c0 + lane] : 0, have, min(64, n_ovf - c0));
+    }
 #pragma unroll
     for (int d = 16; d <= 32; d <<= 1) {
         mx.x = fmaxf(mx.x, __shfl_xor(mx.x, d, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, d, 64));
         mx.z = fmaxf(mx.z, __shfl_xor(mx.z, d, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, d, 64));
         my = fmaxf(my, __shfl_xor(my, d, 64));
-        n += __shfl_xor(n, d, 64); sx += __shfl_xor(sx, d, 64); sy += __shfl_xor(sy, d, 64);
+    }
+    unsigned long long sx64 = sx, sy64 = sy;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        n += __shfl_xor(n, d, 64); sx64 += __shfl_xor(sx64, d, 64); sy64 += __shfl_xor(sy64, d, 64);
         ts += __shfl_xor(ts, d, 64); mi = max(mi, __shfl_xor(mi, d, 64));
+    }
+    if (bitmap) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { bm0 |= __shfl_xor(bm0, d, 64); bm1 |= __shfl_xor(bm1, d, 64); bm2 |= __shfl_xor(bm2, d, 64); }
+        if (lane == 0) { unsigned* w = bitmap + (size_t)slot * 3; w[0] = bm0; w[1] = bm1; w[2] = bm2; }
+        if (bad) atomicOr(counters, EVAD_FLAG_POOL_WINDOW);
     }
     if (grp == 0) {
         float* f = feat + (size_t)slot * 80;
         f[q] = my;
         *(float4*)(f + 16 + 4 * q) = mx;
-        if (q == 0) { cnt[slot] = n; sums[2 * (size_t)slot] = sx; sums[2 * (size_t)slot + 1] = sy; tsum[slot] = ts; maxidx[slot] = mi; }
+        if (q == 0) { cnt[slot] = n; sums[2 * (size_t)slot] = sx64; sums[2 * (size_t)slot + 1] = sy64; tsum[slot] = ts; maxidx[slot] = mi; }
     }
 }
 
 extern "C" int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
                                  const int32_t* key_s, const int32_t* sid, const int32_t* node_slot,
                                  const uint32_t* pix_start, const int32_t* vx_lo, const int32_t* vy_lo,
-                                 const int32_t* ovf_list, const uint32_t* counters, int N, int B, int W, int H, int nx,
+                                 const int32_t* ovf_list, uint32_t* counters, int N, int B, int W, int H, int nx,
                                  int ny, float* feat, uint64_t* sums, double* tsum, uint32_t* cnt, int32_t* maxidx,
+                                 const int32_t* ell_src, const int32_t* deg, const int32_t* node_vox, uint32_t* bitmap,
                                  void* stream) {
     if (!y2 || !map_nhwc || !posn_s || !key_s || !sid || !node_slot || !pix_start || !vx_lo || !vy_lo || !ovf_list ||
-        !counters || !feat || !sums || !tsum || !cnt || !maxidx || N < 0 || B <= 0 || nx <= 0 || ny <= 0)
+        !counters || !feat || !sums || !tsum || !cnt || !maxidx || N < 0 || B <= 0 || nx <= 0 || ny <= 0 ||
+        (bitmap && (!ell_src || !deg || !node_vox || nx > 255 || ny > 255)))
         return EVAD_ERR_ARG;
     int S = nx * ny * (B + 1);
     hipLaunchKernelGGL(k_pool_seg0, dim3(evad_blocks(S, 4)), dim3(256), 0, (hipStream_t)stream, y2, map_nhwc, map_h, map_w,
                        posn_s, key_s, sid, node_slot, pix_start, vx_lo, vy_lo, ovf_list, counters, B, W, H, nx, ny, S, feat,
-                       (unsigned long long*)sums, (unsigned long long*)tsum, cnt, maxidx);
+                       (unsigned long long*)sums, (unsigned long long*)tsum, cnt, maxidx, ell_src, deg, node_vox, bitmap);
     return evad_last_error();
 }
 

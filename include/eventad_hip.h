@@ -142,12 +142,17 @@ int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc
 /* Level-0 pooling without atomics: one wave per voxel slot walks the slot's pixel rows in the pixel CSR
  * (events of a voxel row are contiguous in sorted order), samples the 64-channel CNN map per member and
  * keeps running maxima in registers.  vx_lo i32[nx+1] / vy_lo i32[ny+1] = first pixel of each voxel column
- * / row.  Writes feat f32[S,80] (plain floats: finalize mode 2), sums, tsum, cnt, maxidx for EVERY slot. */
+ * / row.  Writes feat f32[S,80] (plain floats: finalize mode 2), sums, tsum, cnt, maxidx for EVERY slot.
+ * bitmap != NULL: the wave also ORs the marks of all in-edges of the slot's members (ELL rows ell_src / deg, source voxels
+ * node_vox as written by eventad_sort_events) into the slot's three neighbour-bitmap words and stores them -- the
+ * cluster[edge_index] pass of pooling.py:57-61 without atomics and without a pre-zeroed table (replaces the bitmap
+ * argument of eventad_build_ell / eventad_pool_edges_mark_ell); counters[0] receives the window-overflow flag. */
 int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
                       const int32_t* key_s, const int32_t* sid, const int32_t* node_slot, const uint32_t* pix_start,
-                      const int32_t* vx_lo, const int32_t* vy_lo, const int32_t* ovf_list, const uint32_t* counters,
+                      const int32_t* vx_lo, const int32_t* vy_lo, const int32_t* ovf_list, uint32_t* counters,
                       int N, int B, int W, int H, int nx, int ny, float* feat, uint64_t* sums, double* tsum,
-                      uint32_t* cnt, int32_t* maxidx, void* stream);
+                      uint32_t* cnt, int32_t* maxidx, const int32_t* ell_src, const int32_t* deg, const int32_t* node_vox,
+                      uint32_t* bitmap, void* stream);
 int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const double* tsum, const uint32_t* cnt,
                           const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
                           int feat_mode /* 0 ordered-uint max, 1 mean, 2 float max */, int level0, int W, int H, float wh_inv_x, float wh_inv_y, uint32_t* occ_scan,

@@ -157,8 +157,8 @@ def test_workspace_of_a_larger_batch_is_reused_for_a_smaller_one():
 def test_rarely_taken_kernel_paths_give_the_same_results():
     """Code paths the default configuration never takes, each against the default path or the oracle:
     (1) slot tables beyond one pass of the single-workgroup scan kernel (nx*ny*(B+1) > 131072: B >= 58 clips) go through
-        eventad_pool_finalize + eventad_pool_edges_emit; (2) fused_mark = False marks pool1's neighbour bitmap in a second
-        pass over the ELL (eventad_pool_edges_mark_ell); (3) a neighbour cap other than 16 takes the generic edge-search
+        eventad_pool_finalize + eventad_pool_edges_emit; (2) pool1's neighbour bitmap marked by the edge search kernels (fused_mark = "edge_search",
+        both kernels) or in a pass of its own over the ELL (False, eventad_pool_edges_mark_ell) instead of by the pooling kernel; (3) a neighbour cap other than 16 takes the generic edge-search
         kernel of eventad_build_ell."""
     import torch
     from oracle import dagr_ref, graph as G
@@ -178,21 +178,22 @@ def test_rarely_taken_kernel_paths_give_the_same_results():
     n4 = int(res["out4"]["n_dev"].item())
     assert n4 == o4.x.shape[0] and torch.equal(res["out4"]["batch"][:n4].cpu().long(), o4.batch)
     assert torch.allclose(res["out4"]["x"][:n4].cpu(), o4.x, atol=1e-3, rtol=1e-3)
-    # (2) separate mark pass == fused mark
+    # (2) the three places that can mark the bitmap give the same pooled graph
     W = H = 64; B = 3; n = 3000
     data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True))
     outs = []
-    for fused in (True, False):
+    for fused, variant in ((True, None), (False, None), ("edge_search", 0), ("edge_search", 1)):
         nb = NativeBackbone(sd, W, H, dev)
-        nb.fused_mark = fused
+        nb.fused_mark, nb.ell_variant = fused, variant
         res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
         torch.cuda.synchronize()
         L = nb.ws["levels"][0]
         e = int(L.e_dev.item())
         outs.append((L.csr_src[:e].clone(), L.rowptr[: int(L.n_dev.item()) + 1].clone(),
                      res["out4"]["x"][: int(res["out4"]["n_dev"].item())].clone()))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
     # (3) neighbour cap 8: generic kernel vs the oracle's builder with K = 8
     ws, N, g = nb.ws, data.pos.shape[0], nb.geom
     K = 8
