@@ -556,7 +556,7 @@ __global__ __launch_bounds__(ELL_TILE) void k_build_ell_reg(const int2* __restri
     __shared__ int s_perm[ELL_TILE];
     __shared__ int s_cnt[64];
     __shared__ int s_mm[2];
-    const int tid = threadIdx.x, r0 = blockIdx.x * ELL_TILE + tid;
+    const int tid = threadIdx.x, r0 = blockIdx.x * blockDim.x + tid;     // BY_RANK: blockDim.x == ELL_TILE
     int r = r0;
     if (BY_RANK) {
     if (tid < 64) s_cnt[tid] = 0;
@@ -810,9 +810,10 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
 #undef EVAD_RS
     } else if (fast) {
-        const dim3 tgrid(evad_blocks(N, ELL_TILE));
         const bool by_rank = (double)N >= 2.0 * (double)B * W * H;          // >= 2 events per pixel on average
-#define EVAD_REG(MK, BR) hipLaunchKernelGGL((k_build_ell_reg<MK, BR>), tgrid, dim3(ELL_TILE), 0, st, (const int2*)ev2, key_s, pix_start, \
+        const int threads = by_rank ? ELL_TILE : 256;
+        const dim3 tgrid(evad_blocks(N, threads));
+#define EVAD_REG(MK, BR) hipLaunchKernelGGL((k_build_ell_reg<MK, BR>), tgrid, dim3(threads), 0, st, (const int2*)ev2, key_s, pix_start, \
                                counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters)
         if (bitmap) { if (by_rank) EVAD_REG(true, true); else EVAD_REG(true, false); }
         else        { if (by_rank) EVAD_REG(false, true); else EVAD_REG(false, false); }

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
             }
         }
         const int iters = (count + 3) >> 2;
+#pragma unroll 2
         for (int it = 0; it < iters; ++it) {
             const int m = it * 4 + grp;                      // < 64 whenever it < iters
             const int m_r = __shfl(r, m, 64), m_mask = __shfl(cmask, m, 64), m_off = __shfl(off, m, 64);
