@@ -23,12 +23,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
-# C-ABI call -> kernel name in the rocprofv3 traces / profiles/*_hbm_traffic.json
-KERNEL_OF = {"eventad_build_ell#1": "k_build_ell_rowscan<3, true>", "eventad_l1_conv1#1": "k_l1_conv<20, false, true>",
-             "eventad_l1_conv2#1": "k_l1_conv<16, true, true>", "eventad_pool_seg0#1": "k_pool_seg0"}
+# C-ABI call -> prefixes of the kernel names it launches, as they appear in the rocprofv3 traces / profiles/*_hbm_traffic.json
+# (the template arguments depend on the configuration: row scan or spiral walk, LUT fully or partly in LDS)
+KERNEL_OF = {"eventad_build_ell#1": ("k_build_ell_rowscan", "k_build_ell_reg"), "eventad_l1_conv1#1": ("k_l1_conv<20",),
+             "eventad_l1_conv2#1": ("k_l1_conv<16",), "eventad_pool_seg0#1": ("k_pool_seg0(", "k_pool_seg0")}
 
 
-def pmc_traffic(config, kernel):
+def pmc_traffic(config, prefixes):
     """HBM bytes per launch from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     rocprofv3 --pmc runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py)."""
     import glob
@@ -37,8 +38,9 @@ def pmc_traffic(config, kernel):
             d = json.load(open(f))
         except Exception:
             continue
-        if kernel in d:
-            return d[kernel]["hbm_bytes_per_launch"], os.path.basename(f)
+        hits = [k for k in d if any(k.startswith(p) for p in prefixes) and not k.startswith("k_pool_seg0_bwd")]
+        if hits:
+            return max(d[k]["hbm_bytes_per_launch"] for k in hits), os.path.basename(f)
     return None, None
 
 
@@ -71,7 +73,8 @@ def algorithmic_bytes(N, E, B, W, H):
         "eventad_build_ell#1": 16 * N + 8 * E,                                   # S1
         "eventad_l1_conv1#1": E * (76 + 8) + N * (76 + 64),                      # S3
         "eventad_l1_conv2#1": E * (64 + 8) + N * (64 + 76 + 64),                 # S4
-        "eventad_pool_seg0#1": 256 * N + maps1 + N * (320 + 16) + B * 2240 * (320 + 12),   # S5 + S6
+        # S5 + S6, plus the pooled-edge marks the kernel now does: the ELL row + degree per event, one voxel id per edge
+        "eventad_pool_seg0#1": 256 * N + maps1 + N * (320 + 16) + B * 2240 * (320 + 12) + 68 * N + 4 * E,
     }
 
 
@@ -221,7 +224,7 @@ def main():
             name = max(ab, key=lambda k: summ[k][1])
             ms = summ[name][1]
             ach = ab[name] / (ms * 1e-3) / 1e9
-            traffic, src = pmc_traffic(a.config, KERNEL_OF.get(name, ""))
+            traffic, src = pmc_traffic(a.config, KERNEL_OF.get(name, ()))
             out["roofline"] = {"bound": "hbm", "kernel": name.split("#")[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                                "algorithmic_bytes": ab[name], "avg_launch_ms": round(ms, 4)}

@@ -80,12 +80,19 @@ def test_single_event_batch():
     _run(EventBatch.from_clips(_clips(W, H, [1])), W, H, 1)
 
 
-def test_full_size_c2_properties():
-    """At BASELINE.json's C2 size the oracle is too slow for the CI budget: check invariants instead."""
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C5"])
+def test_full_size_properties(cfg):
+    """At BASELINE.json's full sizes (C2: 400k events; C3: 6.4M events, spiral-walk edge search; C5: 32M events at 640x480,
+    search radius 7, rank-dealt spiral walk and the partly-in-LDS LUT) the oracle is too slow for the CI budget: check
+    invariants of the graph and of every pooled level instead."""
     from eventad_amd.backbone import NativeBackbone
     from eventad_amd.dagr.utils.buffers import format_data
-    W, H, n, B, _ = synthetic.CONFIGS["C2"]
-    data = format_data(synthetic.make_config_batch("C2").to("cuda"))
+    W, H, n, B, live = synthetic.CONFIGS[cfg]
+    data = format_data(synthetic.make_config_batch(cfg).to("cuda"))
+    if live:                                                 # the trunk has its own tests: random maps of its output shapes
+        g = torch.Generator().manual_seed(0)
+        data.image_feats = [torch.randn(B, c, h, w, generator=g).to("cuda")
+                            for c, (h, w) in zip(synthetic.FEATURE_CHANNELS, synthetic.feature_map_sizes(W, H))]
     nb = NativeBackbone(weights.random_graph_state(), W, H, torch.device("cuda:0"))
     res = nb.forward(data.pos, data.x, data.batch, B, data.image_feats)
     torch.cuda.synchronize()
@@ -111,13 +118,16 @@ def test_full_size_c2_properties():
     t_us = (data.pos[:, 2] * 1e6)
     assert float((t_us[d_ids[live]] - t_us[s_ids[live]]).max()) <= 10000 + 1               # inside the time window
     px, py = key_s % W, (key_s // W) % H
-    assert int((px[src.clamp(min=0)] - px.view(-1, 1)).abs()[live].max()) <= 3              # inside the radius
-    assert int((py[src.clamp(min=0)] - py.view(-1, 1)).abs()[live].max()) <= 3
+    R = nb.geom.radius_px
+    assert int((px[src.clamp(min=0)] - px.view(-1, 1)).abs()[live].max()) <= R              # inside the radius
+    assert int((py[src.clamp(min=0)] - py.view(-1, 1)).abs()[live].max()) <= R
+    del s_ids, d_ids, live, src
     caps = [2240, 560, 140, 35]
+    at_window_end = int((data.pos[:, 2] >= 1.0).sum())       # events at t == time_window open voxels in the plane after their clip's
     for lv, L in enumerate(ws["levels"]):
         nl = int(L.n_dev.item())
         cnt = torch.bincount(L.nbatch[:nl].long(), minlength=B)
-        assert int(cnt.max()) <= caps[lv] + 1 and nl > 0                                    # voxel grid bound (+ the t==T quirk)
+        assert int(cnt.max()) <= caps[lv] + at_window_end and nl > 0                        # voxel grid bound (+ the t==T quirk)
         e = int(L.e_dev.item())
         rp = L.rowptr[: nl + 1].long()
         assert int(rp[-1]) == e and bool((rp[1:] >= rp[:-1]).all())
