@@ -455,3 +455,19 @@ extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, f
                        (float)(1.0 - lr * weight_decay), state);
     return evad_last_error();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Streams restricted to a set of CUs (default priority): the training step can give the head's chain of small launches a
+// few CUs of its own, so that its workgroups do not queue behind the chip-wide grids of the event-level kernels.
+// mask: bit i set = CU i may be used; words = number of 32-bit words.
+extern "C" int eventad_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out) {
+    if (!mask || words < 1 || !stream_out) return EVAD_ERR_ARG;
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); return -2; }
+    *stream_out = (void*)s;
+    return EVAD_OK;
+}
+extern "C" int eventad_stream_destroy(void* stream) {
+    if (!stream) return EVAD_ERR_ARG;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? EVAD_OK : -2;
+}

@@ -46,6 +46,12 @@ class TrainStep:
         self.graph = None
         self._retired = []                # superseded graphs stay alive: buffers first allocated under them stay mapped
         self._dual = None
+        # two-stream modes: CUs set aside for the head's stream (0 = both streams may use every CU).  The head is a chain of
+        # ~70 small dependent launches; sharing CUs with the backbone's chip-wide grids, each of them queues behind
+        # whatever grid is being dispatched and the chain stretches from 0.55 to 1.05 ms (C2) -- longer than the backbone.
+        self.head_cus = int(os.environ.get("EVENTAD_HEAD_CUS", "-1"))
+        if self.head_cus < 0:
+            self.head_cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count // 8
 
     # ------------------------------------------------------------------ pieces
     def _head_update(self, feats, head_in, labels=None):
@@ -115,7 +121,28 @@ class TrainStep:
     def _streams(self):
         if getattr(self, "_sg", None) is None:
             # both at the default priority: work on streams of different priorities has hung on this platform
-            self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream()
+            n_head = self.head_cus
+            if n_head > 0:
+                # disjoint CU sets: the head's small dependent launches do not queue behind the backbone's chip-wide grids
+                import ctypes
+                from ._lib import call
+                total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+                words = (total + 31) // 32
+                hm, bm = (ctypes.c_uint32 * words)(), (ctypes.c_uint32 * words)()
+                # mask bit i is CU i/8 of XCD i%8 on this part: the first n bits take n/8 CUs from every XCD (measured:
+                # 32 CUs taken from ONE XCD instead run 3x slower; 16 / 24 / 28 / 32 / 40 CUs: 7.8k / 8.7k / 8.8k / 9.0k / 8.1k clips/s)
+                for cu in range(total):
+                    (hm if cu < n_head else bm)[cu // 32] |= 1 << (cu % 32)
+                self._raw_streams = []
+                out = []
+                for m in (bm, hm):
+                    h = ctypes.c_void_p()
+                    call("eventad_stream_create_cu_mask", ctypes.cast(m, ctypes.c_void_p), words, ctypes.byref(h))
+                    self._raw_streams.append(h)
+                    out.append(torch.cuda.ExternalStream(h.value))
+                self._sg, self._sh = out
+            else:
+                self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream()
         return self._sg, self._sh
 
     def prime(self, data):
@@ -143,47 +170,56 @@ class TrainStep:
         self._feats_cur.copy_(feats_next)
         return loss, norm
 
-    # ---- the same pipeline as TWO single-branch hipGraphs on two streams coupled only by events.  The step object owns
-    # the static inputs of both stages: `in_b` (a whole batch: the backbone graph's input) and `in_h` (the boxes of the
-    # batch whose features the head graph consumes).  Per replay k:
-    #     stream H: wait(backbone k done); feats_cur <- feats_next; in_h <- boxes of in_b; record(handed); head graph(k)
-    #     stream G: wait(handed); in_b <- batch k+1 (if given); backbone graph(k+1); record(backbone done)
-    # so the head always sees the boxes and labels of the batch that produced its features, and a new batch is copied in
-    # only after the previous one has been handed over.
+    # ---- the same pipeline as single-branch hipGraphs on two streams coupled only by events, double-buffered by step
+    # parity p = k % 2 so that nothing is copied between the stages and the backbone of batch k+1 starts the moment the
+    # backbone of batch k ends:
+    #     backbone graph p  writes its own feature tensor feats[p]            (stream G)
+    #     head graph p      reads feats[p] and the boxes / labels in_h[p]     (stream H)
+    # Per replay k (p = k % 2, p' = (k+1) % 2):
+    #     stream H: wait(backbone k done); head graph p; record(head k done)
+    #     stream G: wait(head k-1 done: it was the last reader of feats[p'] and in_h[p']); in_b, in_h[p'] <- batch k+1 (if
+    #               given); backbone graph p'; record(backbone k+1 done)
+    # The step object owns the static inputs: `in_b` (a whole batch: the backbone graphs' input) and `in_h[0..1]` (the
+    # boxes of the batch whose features the head graph of that parity consumes), so the head always sees the boxes and
+    # labels of the batch that produced its features.
     def capture_dual(self, data, warmup=3):
-        """data: the first batch (formatted, on the device).  Captures both graphs on copies of it and fills the pipeline
-        with its features.  Every later batch must have the same shapes (events N, boxes M, clips B)."""
+        """data: the first batch (formatted, on the device).  Captures the graphs on copies of it and starts the backbone
+        pass of that batch.  Every later batch must have the same shapes (events N, boxes M, clips B)."""
         d = self._dual = {}
         in_b = d["in_b"] = data.clone()
-        in_h = d["in_h"] = _HeadInputs(in_b)
+        in_h = d["in_h"] = [_HeadInputs(in_b), _HeadInputs(in_b)]
+        d["in_b_id"], d["in_h_id"] = 0, [0, 0]                 # which loaded batch each buffer holds
         self.prime(in_b)
         snap = self.snapshot()                                 # warm-up steps are undone: the first replay consumes `data`
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.pipelined_step(in_h, None, in_b)
+                self.pipelined_step(in_h[0], None, in_b)
         torch.cuda.current_stream().wait_stream(side)
         self.restore(snap)
         torch.cuda.synchronize()
         self._pin_workspaces()
-        gb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        d["gb"], d["gh"], d["feats"], d["out"] = [], [], [], []
         with torch.no_grad():
-            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                d["feats_next"] = self.model.extract_features(in_b, frames=(1,))
-            with torch.cuda.graph(gh, capture_error_mode="thread_local"):
-                self._g_loss, self._g_norm = self._head_update(self._feats_cur, in_h)
-        d["gb"], d["gh"] = gb, gh
-        d["ev_b"], d["ev_c"] = torch.cuda.Event(), torch.cuda.Event()
+            for p in range(2):
+                gb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                    feats = self.model.extract_features(in_b, frames=(1,))
+                with torch.cuda.graph(gh, capture_error_mode="thread_local"):
+                    out = self._head_update(feats, in_h[p])
+                d["gb"].append(gb); d["gh"].append(gh); d["feats"].append(feats); d["out"].append(out)
+        d["ev_b"] = [torch.cuda.Event(), torch.cuda.Event()]
+        d["ev_h"] = [torch.cuda.Event(), torch.cuda.Event()]
+        d["k"], d["drained"] = 0, False
         main = torch.cuda.current_stream()
         sg, sh = self._streams()
         sg.wait_stream(main); sh.wait_stream(main)
-        with torch.cuda.stream(sg):                            # features of the first batch, as prime() left them
-            gb.replay()
-            d["ev_b"].record(sg)
-        with torch.cuda.stream(sh):
-            d["ev_c"].record(sh)
-        return gb, gh
+        with torch.cuda.stream(sg):                            # the first batch enters the pipeline
+            d["gb"][0].replay()
+            d["ev_b"][0].record(sg)
+        self._g_loss, self._g_norm = d["out"][0]
+        return d["gb"], d["gh"]
 
     @staticmethod
     def load_into(in_b, batch):
@@ -200,12 +236,25 @@ class TrainStep:
             for dst, src in zip(in_b.image_feats, batch.image_feats):
                 dst.copy_(src, non_blocking=True)
 
+    def _issue_backbone(self, d, p_next, next_batch, sg):
+        """Stream G part of a step: load the next batch (if any), backbone graph of parity p_next."""
+        with torch.cuda.stream(sg):
+            sg.wait_event(d["ev_h"][p_next])                   # the last reader of feats[p_next] / in_h[p_next] is done
+            if next_batch is not None:
+                self.load_into(d["in_b"], next_batch)
+                d["in_b_id"] += 1
+            if d["in_h_id"][p_next] != d["in_b_id"]:
+                d["in_h"][p_next].copy_from(d["in_b"])
+                d["in_h_id"][p_next] = d["in_b_id"]
+            d["gb"][p_next].replay()
+            d["ev_b"][p_next].record(sg)
+
     def replay_dual(self, next_batch=None, join=True):
         """One pipelined step: head update of the batch loaded by the previous call (or capture_dual) || backbone of
         `next_batch` (formatted; on the device or in pinned host memory; None = run the resident batch again).
-        Returns (loss, grad_norm) of the batch the head consumed -- static device tensors, valid after a synchronisation.
-        join=False: no per-step barrier with the caller's stream; call flush() -- or synchronise -- before reading results
-        or re-using the memory of a `next_batch` passed earlier."""
+        Returns (loss, grad_norm) of the batch the head consumed -- static device tensors of that step parity, valid after
+        a synchronisation and until the call after next.  join=False: no per-step barrier with the caller's stream; call
+        flush() -- or synchronise -- before reading results or re-using the memory of a `next_batch` passed earlier."""
         d = self._dual
         main = torch.cuda.current_stream()
         sg, sh = self._streams()
@@ -213,36 +262,41 @@ class TrainStep:
             sg.wait_stream(main)                               # next_batch was produced on the caller's stream
         if join:
             sh.wait_stream(main)
+        if d["drained"]:                                       # after flush(): restart the pipeline with this batch
+            d["drained"] = False
+            self._issue_backbone(d, d["k"] % 2, next_batch, sg)
+            if join:
+                main.wait_stream(sg)
+            return None
+        p = d["k"] % 2
         with torch.cuda.stream(sh):
-            sh.wait_event(d["ev_b"])
-            self._feats_cur.copy_(d["feats_next"])
-            d["in_h"].copy_from(d["in_b"])
-            d["ev_c"].record(sh)
-            d["gh"].replay()
-        with torch.cuda.stream(sg):
-            sg.wait_event(d["ev_c"])
-            if next_batch is not None:
-                self.load_into(d["in_b"], next_batch)
-            d["gb"].replay()
-            d["ev_b"].record(sg)
+            sh.wait_event(d["ev_b"][p])
+            d["gh"][p].replay()
+            d["ev_h"][p].record(sh)
+        self._issue_backbone(d, 1 - p, next_batch, sg)
+        d["k"] += 1
         if join:
             main.wait_stream(sg); main.wait_stream(sh)
-        return self._g_loss, self._g_norm
+        self._g_loss, self._g_norm = d["out"][p]
+        return d["out"][p]
 
     def flush(self):
-        """Drain the pipeline: head update of the last loaded batch, no new backbone pass.  -> (loss, grad_norm)."""
+        """Drain the pipeline: head update of the last loaded batch, no new backbone pass.  -> (loss, grad_norm).
+        The next replay_dual(batch) restarts the pipeline with `batch` (and returns None: no head update in that call)."""
         d = self._dual
         main = torch.cuda.current_stream()
         sg, sh = self._streams()
         sh.wait_stream(main)
+        p = d["k"] % 2
         with torch.cuda.stream(sh):
-            sh.wait_event(d["ev_b"])
-            self._feats_cur.copy_(d["feats_next"])
-            d["in_h"].copy_from(d["in_b"])
-            d["ev_c"].record(sh)
-            d["gh"].replay()
+            sh.wait_event(d["ev_b"][p])
+            d["gh"][p].replay()
+            d["ev_h"][p].record(sh)
+        d["k"] += 1
+        d["drained"] = True
         main.wait_stream(sh); main.wait_stream(sg)
-        return self._g_loss, self._g_norm
+        self._g_loss, self._g_norm = d["out"][p]
+        return d["out"][p]
 
     def check(self):
         """Lazy, synchronising: raises if a step saw a non-finite gradient norm (the reference raises at

@@ -313,6 +313,12 @@ int eventad_pool_seg0_bwd(const float* y2, const float* map_nhwc, int map_h, int
 int eventad_sample_bwd(const float* g, int ldg, int C, const float* posn_s, const uint32_t* pix_start, int N, int B,
                        int W, int H, int map_h, int map_w, float* dmap, void* stream);
 
+/* ---- (J) streams restricted to a CU set (no counterpart in the reference) ------------------------------------------ */
+/* A default-priority HIP stream whose kernels may only use the CUs whose bit is set in mask (u32[words], bit i = CU i).
+ * TrainStep uses a pair of them with disjoint masks for the backbone graph and the head graph. */
+int eventad_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
+int eventad_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif
