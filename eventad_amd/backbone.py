@@ -51,6 +51,7 @@ class NativeBackbone:
         # who fills pool1's neighbour bitmap: True = the wave-per-voxel pooling kernel (no atomics; default),
         # "edge_search" = the edge search while the ELL row is in registers (atomics), False = a pass of its own over the ELL
         self.fused_mark = True
+        self._tail_arena_clean = False
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
 
@@ -109,10 +110,19 @@ class NativeBackbone:
         # zero-initialised scratch of the event-level stage, back to back so eventad_sort_events clears it with ONE
         # fill: [counters(4) | pixel histogram(P+1) | pool1 neighbour bitmap(3*S0) | work counters of the two convs (2 x 256)]
         S0_ = g.grid[0][0] * g.grid[0][1] * (B + 1)
-        front_arena = torch.zeros(4 + P + 1 + 3 * S0_ + 512 + 32, dtype=torch.int32, device=dev)
+        work_at = (4 + P + 1 + 3 * S0_ + 31) // 32 * 32        # 128-byte aligned
+        # the pooled stage's zero-initialised scratch (slot tables + neighbour bitmaps of pools 2..4, error flags) lies right
+        # behind it, so that a front() pass clears both with the same fill; tail() alone (a hand-off set from elsewhere)
+        # clears its part itself
+        tail_words = sum(g.grid[lv][0] * g.grid[lv][1] * (B + 1) * (128 + 8 + 3) + 8 for lv in range(1, 4)) + 4
+        tail_at = (work_at + 512 + 3) // 4 * 4
+        self._front_zero_words = tail_at + tail_words - (4 + P + 1)
+        both = torch.zeros(tail_at + tail_words, dtype=torch.int32, device=dev)
+        front_arena = both[:work_at + 512]
         ws = dict(
             front_arena=front_arena, counters=front_arena[:4], pix_count=front_arena[4:4 + P + 1],
-            bitmap0=front_arena[4 + P + 1:4 + P + 1 + 3 * S0_].view(S0_, 3), l1_work=front_arena[(4 + P + 1 + 3 * S0_ + 31) // 32 * 32:][:512],     # 128-byte aligned
+            bitmap0=front_arena[4 + P + 1:4 + P + 1 + 3 * S0_].view(S0_, 3), l1_work=front_arena[work_at:work_at + 512],
+            slot_vd0=i32(S0_),                               # pool1: occupied << 31 | pooled in-edges per slot
             key=i32(N), tq=i32(N), bev=i32(N), pix_start=i32(P + 1),
             scan_tmp=i32(2 * (max(P, 1 << 16) // 2048 + 4)), sid_tmp=i32(N), sid=i32(N),
             key_s=i32(N), ts_s=i32(N), ev2=i32(N, 2), posn_s=f32(N, 3), x0s=f32(N, 20),
@@ -144,8 +154,7 @@ class NativeBackbone:
         # zero-initialised scratch of the pooled stage (slot tables + neighbour bitmaps of pools 2..4, error flags): ONE
         # fill at the start of tail() instead of two memsets per level.  (Separate from the front arena: the two
         # stages may run concurrently on different batches.)
-        tail_words = sum(g.grid[lv][0] * g.grid[lv][1] * (B + 1) * (128 + 8 + 3) + 8 for lv in range(1, 4)) + 4
-        tail_arena = torch.zeros(tail_words, dtype=torch.int32, device=dev)
+        tail_arena = both[tail_at:]
         ws["tail_arena"], ws["flags_tail"] = tail_arena, tail_arena[tail_words - 4:]
         toff = 0
         levels = []
@@ -245,13 +254,13 @@ class NativeBackbone:
             self._c("eventad_nchw_to_nhwc_group", len(todo), ctypes.cast(d, ctypes.c_void_p), st)
         assert [m.shape[3] for m in maps] == FEATURE_CHANNELS and all(m.shape[0] == B for m in maps)
         w, K = self.w, g.max_neighbors
-        L0_ = ws["levels"][0]
+        self._tail_arena_clean = True
         self._c("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
              N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
              ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["counters"]),
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
-             ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), 3 * L0_.S + 512 + 32, st)     # also clears counters, histogram, pool1 bitmap, work counters
+             ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), self._front_zero_words, st)   # also clears counters, histogram, pool1 bitmap, work counters
         sw = self.ell_variant
         if sw is None:
             window = (2 * g.radius_px + 1) ** 2 * N / max(B * g.W * g.H, 1)         # mean events per search window
@@ -272,7 +281,8 @@ class NativeBackbone:
                 ptr(ws["key_s"]), ptr(ws["sid"]), ptr(ws["node_slot0"]), ptr(ws["pix_start"]), ptr(self.vox_tabs[2]),
                 ptr(self.vox_tabs[3]), ptr(ws["ovf_list"]), ptr(ws["counters"]), N, B, g.W, g.H, L.nx, L.ny,
                 ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["ell_src"]), ptr(ws["deg"]),
-                ptr(ws["node_vox0"]), ptr(L.bitmap) if self.fused_mark is True else None, st)
+                ptr(ws["node_vox0"]), ptr(L.bitmap) if self.fused_mark is True else None,
+                ptr(ws["slot_vd0"]) if self.fused_mark is True else None, st)
         small = L.S <= 131072                               # both scans of the level fit the single-workgroup kernel
         if not self.fused_mark:
             self._c("eventad_pool_edges_mark_ell", ptr(ws["ell_src"]), ptr(ws["deg"]), ptr(ws["node_slot0"]), N, K,
@@ -281,7 +291,8 @@ class NativeBackbone:
             self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
                  ptr(L.bitmap), L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ), _rp(hand.x), L.ldx,
                  _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.n_dev),
-                 _rp(hand.rowptr), _rp(hand.csr_src), _rp(hand.csr_dxy), _rp(hand.e_dev), st)
+                 _rp(hand.rowptr), _rp(hand.csr_src), _rp(hand.csr_dxy), _rp(hand.e_dev),
+                 ptr(ws["slot_vd0"]) if self.fused_mark is True else None, st)
         else:
             self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
                  L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
@@ -304,7 +315,10 @@ class NativeBackbone:
         G0.x, G0.npos, G0.npix, G0.nbatch, G0.n_dev, G0.e_dev = hand.x, hand.npos, hand.npix, hand.nbatch, hand.n_dev, hand.e_dev
         G0.rowptr, G0.csr_src, G0.csr_dxy = hand.rowptr, hand.csr_src, hand.csr_dxy
         view = [G0] + levels[1:]
-        ws["tail_arena"].zero_()
+        if self._tail_arena_clean:
+            self._tail_arena_clean = False                   # front() cleared it together with its own scratch
+        else:
+            ws["tail_arena"].zero_()
         out3 = None
         for lv in range(4):
             L = view[lv]
@@ -321,7 +335,7 @@ class NativeBackbone:
                     self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
                          _rp(Lp.nbatch), ptr(L.bitmap), L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),
                          ptr(L.x), L.ldx, ptr(L.npos), ptr(L.npix), ptr(L.nbatch), ptr(L.node_slot), ptr(L.slot2node), ptr(L.n_dev),
-                         ptr(L.rowptr), ptr(L.csr_src), ptr(L.csr_dxy), ptr(L.e_dev), st)
+                         ptr(L.rowptr), ptr(L.csr_src), ptr(L.csr_dxy), ptr(L.e_dev), None, st)
                 else:
                     self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), _rp(Lp.nbatch),
                          L.nx, L.ny, B, L.C, mean, 0, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ),

@@ -6,6 +6,7 @@
 #define EVAD_OK 0
 #define EVAD_ERR_ARG (-1)
 #define EVENTAD_ERR_TOO_LARGE (-3)
+#define EVAD_SCAN_TILE 1024         // slots per workgroup of the tiled slot scans (pool.hip)
 
 // error-flag bits written by kernels into a caller-owned u32 word (checked lazily by the host)
 #define EVAD_FLAG_T_NOT_MONOTONE 1u   // timestamps not non-decreasing in event order inside a clip

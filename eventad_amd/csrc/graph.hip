@@ -235,6 +235,50 @@ __global__ void k_scan_add(unsigned* __restrict__ out, const unsigned* __restric
     if (i < n) out[i] += tile_sums[i / SCAN_TILE];
 }
 
+// Second and last launch of the scan when there are few tiles: the workgroup of tile t adds up the totals of the tiles
+// before it itself (a few loads per thread) instead of waiting for a single-workgroup scan of the totals; the last
+// workgroup also writes the grand total and the maximum.
+#define SCAN_FUSED_MAX_TILES 8192
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_add_fused(unsigned* __restrict__ out, const unsigned* __restrict__ tile_sums,
+                                                                 int n_tiles, long long n, const unsigned* __restrict__ tile_max,
+                                                                 unsigned* __restrict__ max_out) {
+    __shared__ unsigned s_sum[SCAN_THREADS / 64], s_max[SCAN_THREADS / 64];
+    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool last = tile == n_tiles - 1;
+    const int upto = last ? n_tiles : tile;                  // the last workgroup needs the grand total as well
+    unsigned acc = 0, own = 0, m = 0;
+    for (int u = tid; u < upto; u += SCAN_THREADS) {
+        const unsigned v = tile_sums[u];
+        if (u < tile) acc += v; else own += v;
+        if (last && tile_max) m = max(m, tile_max[u]);
+    }
+    unsigned both = acc + own;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        acc += __shfl_xor(acc, d, 64); both += __shfl_xor(both, d, 64); m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
+    }
+    if (lane == 0) { s_sum[wv] = acc; s_max[wv] = m; }
+    __syncthreads();
+    unsigned base = 0, mm = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) { base += s_sum[w]; mm = max(mm, s_max[w]); }
+    if (last) {
+        __shared__ unsigned s_all[SCAN_THREADS / 64];
+        if (lane == 0) s_all[wv] = both;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < SCAN_THREADS / 64; ++w) tot += s_all[w];
+            out[n] = tot;
+            if (max_out) *max_out = mm;
+        }
+    }
+    if (tile == 0) return;                                   // base 0
+    const long long i0 = (long long)tile * SCAN_TILE + (long long)tid * SCAN_ITEMS;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (i0 + k < n) out[i0 + k] += base;
+}
+
 // out has n+1 entries (out[n] = grand total); tile_sums needs ceil(n/2048) entries.  in may alias out.
 // max_out (nullable): also max(in); tile_sums then needs 2*ceil(n/2048) entries.
 int evad_exclusive_scan_max(const unsigned* in, unsigned* out, unsigned* tile_sums, long long n, unsigned* max_out, hipStream_t st) {
@@ -242,6 +286,10 @@ int evad_exclusive_scan_max(const unsigned* in, unsigned* out, unsigned* tile_su
     int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     unsigned* tile_max = max_out ? tile_sums + tiles : nullptr;
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(SCAN_THREADS), 0, st, in, out, tile_sums, n, tile_max);
+    if (tiles <= SCAN_FUSED_MAX_TILES) {
+        hipLaunchKernelGGL(k_scan_add_fused, dim3(tiles), dim3(SCAN_THREADS), 0, st, out, tile_sums, tiles, n, tile_max, max_out);
+        return evad_last_error();
+    }
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, tiles, out + n, tile_max, max_out);
     if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(evad_blocks(n, 256)), dim3(256), 0, st, out, tile_sums, n);
     return evad_last_error();

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     const int* __restrict__ ovf_list, unsigned* __restrict__ counters, int B, int W, int H, int nx, int ny, int S,
     float* __restrict__ feat, unsigned long long* __restrict__ sums, unsigned long long* __restrict__ tsum, unsigned* __restrict__ cnt,
     int* __restrict__ maxidx, const int* __restrict__ ell_src, const int* __restrict__ deg, const int* __restrict__ node_vox,
-    unsigned* __restrict__ bitmap) {
+    unsigned* __restrict__ bitmap, unsigned* __restrict__ slot_vd) {
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= S) return;
     const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
@@ -319,7 +319,11 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     if (bitmap) {
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { bm0 |= __shfl_xor(bm0, d, 64); bm1 |= __shfl_xor(bm1, d, 64); bm2 |= __shfl_xor(bm2, d, 64); }
-        if (lane == 0) { unsigned* w = bitmap + (size_t)slot * 3; w[0] = bm0; w[1] = bm1; w[2] = bm2; }
+        if (lane == 0) {
+            unsigned* w = bitmap + (size_t)slot * 3; w[0] = bm0; w[1] = bm1; w[2] = bm2;
+            // occupied << 31 | pooled in-edges of the slot: what the scans of the finalize stage add up
+            if (slot_vd) slot_vd[slot] = n > 0 ? (0x80000000u | (unsigned)(__popc(bm0) + __popc(bm1) + __popc(bm2))) : 0u;
+        }
         if (bad) atomicOr(counters, EVAD_FLAG_POOL_WINDOW);
     }
     if (grp == 0) {
@@ -336,15 +340,15 @@ extern "C" int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map
                                  const int32_t* ovf_list, uint32_t* counters, int N, int B, int W, int H, int nx,
                                  int ny, float* feat, uint64_t* sums, double* tsum, uint32_t* cnt, int32_t* maxidx,
                                  const int32_t* ell_src, const int32_t* deg, const int32_t* node_vox, uint32_t* bitmap,
-                                 void* stream) {
+                                 uint32_t* slot_vd, void* stream) {
     if (!y2 || !map_nhwc || !posn_s || !key_s || !sid || !node_slot || !pix_start || !vx_lo || !vy_lo || !ovf_list ||
         !counters || !feat || !sums || !tsum || !cnt || !maxidx || N < 0 || B <= 0 || nx <= 0 || ny <= 0 ||
-        (bitmap && (!ell_src || !deg || !node_vox || nx > 255 || ny > 255)))
+        (bitmap && (!ell_src || !deg || !node_vox || nx > 255 || ny > 255)) || (slot_vd && !bitmap))
         return EVAD_ERR_ARG;
     int S = nx * ny * (B + 1);
     hipLaunchKernelGGL(k_pool_seg0, dim3(evad_blocks(S, 4)), dim3(256), 0, (hipStream_t)stream, y2, map_nhwc, map_h, map_w,
                        posn_s, key_s, sid, node_slot, pix_start, vx_lo, vy_lo, ovf_list, counters, B, W, H, nx, ny, S, feat,
-                       (unsigned long long*)sums, (unsigned long long*)tsum, cnt, maxidx, ell_src, deg, node_vox, bitmap);
+                       (unsigned long long*)sums, (unsigned long long*)tsum, cnt, maxidx, ell_src, deg, node_vox, bitmap, slot_vd);
     return evad_last_error();
 }
 
@@ -618,6 +622,54 @@ __global__ __launch_bounds__(1024) void k_slot_scans_small(const unsigned* __res
     for (int j = (int)n + tid; j <= n_max + 1; j += 1024) rowptr[j] = E;     // rows past the last node are empty
 }
 
+// The same two scans with one workgroup per tile of EVAD_SCAN_TILE slots, for a producer that leaves one word per slot
+// (occupied << 31 | in-edges: eventad_pool_seg0's slot_vd): a workgroup adds up the words of all slots (those before its
+// tile give its base), scans its own tile and writes its part of occ_scan / rowptr.  The single workgroup above takes
+// 19 us for level 0 at C2 (20160 slots).
+__global__ __launch_bounds__(EVAD_SCAN_TILE) void k_slot_scans_tiled(const unsigned* __restrict__ slot_vd, int S, int n_max,
+                                                                     unsigned* __restrict__ occ_scan, unsigned* __restrict__ rowptr,
+                                                                     int* __restrict__ n_out, int* __restrict__ e_out) {
+    constexpr int NW = EVAD_SCAN_TILE / 64;
+    __shared__ unsigned s_bn[NW], s_be[NW], s_an[NW], s_ae[NW], s_wn[NW], s_we[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x, ntiles = gridDim.x;
+    const int first = tile * EVAD_SCAN_TILE;
+    unsigned bn = 0, be = 0, an = 0, ae = 0;                 // slots / edges before this tile, and of all tiles
+    for (int u0 = 0; u0 < S; u0 += 8 * EVAD_SCAN_TILE) {    // 8 independent loads in flight per thread
+        unsigned x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int u = u0 + k * EVAD_SCAN_TILE + tid; x[k] = u < S ? slot_vd[u] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = u0 + k * EVAD_SCAN_TILE + tid;
+            const unsigned o = x[k] >> 31, e = x[k] & 0x7fffffffu;
+            an += o; ae += e;
+            if (u < first) { bn += o; be += e; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        bn += __shfl_xor(bn, d, 64); be += __shfl_xor(be, d, 64); an += __shfl_xor(an, d, 64); ae += __shfl_xor(ae, d, 64);
+    }
+    const int s = first + tid;
+    const unsigned x = s < S ? slot_vd[s] : 0u, v = x >> 31, dg = x & 0x7fffffffu;
+    unsigned in_ = v, ie = dg;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned a = __shfl_up(in_, d, 64), b = __shfl_up(ie, d, 64); if (lane >= d) { in_ += a; ie += b; } }
+    if (lane == 0) { s_bn[wv] = bn; s_be[wv] = be; s_an[wv] = an; s_ae[wv] = ae; }
+    if (lane == 63) { s_wn[wv] = in_; s_we[wv] = ie; }
+    __syncthreads();
+    unsigned base_n = 0, base_e = 0, n = 0, E = 0, wn = 0, we = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        base_n += s_bn[w]; base_e += s_be[w]; n += s_an[w]; E += s_ae[w];
+        if (w < wv) { wn += s_wn[w]; we += s_we[w]; }
+    }
+    const unsigned en = base_n + wn + in_ - v, ee = base_e + we + ie - dg;
+    if (s < S) { occ_scan[s] = en; if (v) rowptr[en] = ee; }
+    if (tile == 0 && tid == 0) { occ_scan[S] = n; *n_out = (int)n; *e_out = (int)E; }
+    for (int j = (int)n + first + tid; j <= n_max + 1; j += ntiles * EVAD_SCAN_TILE) rowptr[j] = E;   // rows past the last node are empty
+}
+
 struct SlotPix { int qx, qy; float ox, oy, mt; };
 __device__ __forceinline__ SlotPix slot_pixel(const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ tsum,
                                               unsigned c, int s, int level0, float Wf, float Hf, float whx, float why, bool want_t) {
@@ -692,7 +744,7 @@ extern "C" int eventad_pool_finalize_edges(const uint32_t* feat, const uint64_t*
                                            float wh_inv_y, uint32_t* occ_scan, float* xout, int ldx, float* npos_out,
                                            int32_t* npix_out, int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node,
                                            int32_t* n_out_dev, uint32_t* rowptr, int32_t* csr_src, int32_t* csr_dxy,
-                                           int32_t* e_out_dev, void* stream) {
+                                           int32_t* e_out_dev, const uint32_t* slot_vd, void* stream) {
     if (!feat || !sums || !tsum || !cnt || !maxidx || !batch_of_index || !bitmap || !occ_scan || !xout || !npos_out ||
         !npix_out || !nbatch_out || !node_slot_out || !slot2node || !n_out_dev || !rowptr || !csr_src || !csr_dxy || !e_out_dev ||
         C < 1 || ldx < C + 2 || nx <= 0 || ny <= 0 || B <= 0)
@@ -700,7 +752,11 @@ extern "C" int eventad_pool_finalize_edges(const uint32_t* feat, const uint64_t*
     const int S = nx * ny * (B + 1);
     if (S > 131072) return EVAD_ERR_ARG;                     // larger tables: eventad_pool_finalize + eventad_pool_edges_emit
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_slot_scans_small, dim3(1), dim3(1024), 0, st, cnt, bitmap, S, S, occ_scan, rowptr, n_out_dev, e_out_dev);
+    if (slot_vd)
+        hipLaunchKernelGGL(k_slot_scans_tiled, dim3(evad_blocks(S, EVAD_SCAN_TILE)), dim3(EVAD_SCAN_TILE), 0, st, slot_vd, S, S,
+                           occ_scan, rowptr, n_out_dev, e_out_dev);
+    else
+        hipLaunchKernelGGL(k_slot_scans_small, dim3(1), dim3(1024), 0, st, cnt, bitmap, S, S, occ_scan, rowptr, n_out_dev, e_out_dev);
     const unsigned blocks_fin = evad_blocks((long long)S * C, 256);
     dim3 grid(blocks_fin + evad_blocks(S, 256));
 #define EVAD_FE(MODE) hipLaunchKernelGGL(k_finalize_emit<MODE>, grid, dim3(256), 0, st, occ_scan, cnt, (const unsigned long long*)sums, \

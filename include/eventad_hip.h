@@ -146,13 +146,15 @@ int eventad_pool_scatter(const float* xa, int lda, int Ca, const float* map_nhwc
  * bitmap != NULL: the wave also ORs the marks of all in-edges of the slot's members (ELL rows ell_src / deg, source voxels
  * node_vox as written by eventad_sort_events) into the slot's three neighbour-bitmap words and stores them -- the
  * cluster[edge_index] pass of pooling.py:57-61 without atomics and without a pre-zeroed table (replaces the bitmap
- * argument of eventad_build_ell / eventad_pool_edges_mark_ell); counters[0] receives the window-overflow flag. */
+ * argument of eventad_build_ell / eventad_pool_edges_mark_ell); counters[0] receives the window-overflow flag.
+ * slot_vd != NULL (needs bitmap): u32[S], receives per slot (occupied << 31 | pooled in-edges), which lets
+ * eventad_pool_finalize_edges scan with one workgroup per 1024 slots instead of a single one. */
 int eventad_pool_seg0(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
                       const int32_t* key_s, const int32_t* sid, const int32_t* node_slot, const uint32_t* pix_start,
                       const int32_t* vx_lo, const int32_t* vy_lo, const int32_t* ovf_list, uint32_t* counters,
                       int N, int B, int W, int H, int nx, int ny, float* feat, uint64_t* sums, double* tsum,
                       uint32_t* cnt, int32_t* maxidx, const int32_t* ell_src, const int32_t* deg, const int32_t* node_vox,
-                      uint32_t* bitmap, void* stream);
+                      uint32_t* bitmap, uint32_t* slot_vd, void* stream);
 int eventad_pool_finalize(const uint32_t* feat, const uint64_t* sums, const double* tsum, const uint32_t* cnt,
                           const int32_t* maxidx, const int32_t* batch_of_index, int nx, int ny, int B, int C,
                           int feat_mode /* 0 ordered-uint max, 1 mean, 2 float max */, int level0, int W, int H, float wh_inv_x, float wh_inv_y, uint32_t* occ_scan,
@@ -168,7 +170,7 @@ int eventad_pool_finalize_edges(const uint32_t* feat, const uint64_t* sums, cons
                                 int B, int C, int feat_mode, int level0, int W, int H, float wh_inv_x, float wh_inv_y,
                                 uint32_t* occ_scan, float* xout, int ldx, float* npos_out, int32_t* npix_out,
                                 int32_t* nbatch_out, int32_t* node_slot_out, int32_t* slot2node, int32_t* n_out_dev,
-                                uint32_t* rowptr, int32_t* csr_src, int32_t* csr_dxy, int32_t* e_out_dev, void* stream);
+                                uint32_t* rowptr, int32_t* csr_src, int32_t* csr_dxy, int32_t* e_out_dev, const uint32_t* slot_vd /* NULL, or eventad_pool_seg0's per-slot words */, void* stream);
 int eventad_pool_edges_mark_ell(const int32_t* ell_src, const int32_t* deg, const int32_t* node_slot, int N,
                                 int max_num_neighbors, int nx, int ny, int B, uint32_t* bitmap, uint32_t* flags,
                                 void* stream);
