@@ -46,12 +46,12 @@ class TrainStep:
         self.graph = None
         self._retired = []                # superseded graphs stay alive: buffers first allocated under them stay mapped
         self._dual = None
-        # two-stream modes: CUs set aside for the head's stream (0 = both streams may use every CU).  The head is a chain of
-        # ~70 small dependent launches; sharing CUs with the backbone's chip-wide grids, each of them queues behind
-        # whatever grid is being dispatched and the chain stretches from 0.55 to 1.05 ms (C2) -- longer than the backbone.
+        # two-graph pipeline: CUs set aside for the head's stream.  The head is a chain of ~70 small dependent launches;
+        # sharing CUs with the backbone's chip-wide grids, each of them queues behind whatever grid is being dispatched and
+        # the chain stretches from 0.55 to 1.05 ms (C2) -- longer than the backbone graph.  -1 (default): decided at
+        # capture from the two graphs' stand-alone times (a head that is short against its backbone gets no CUs of its
+        # own: they would only be taken from the backbone); 0: never; n > 0: always n CUs.
         self.head_cus = int(os.environ.get("EVENTAD_HEAD_CUS", "-1"))
-        if self.head_cus < 0:
-            self.head_cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count // 8
 
     # ------------------------------------------------------------------ pieces
     def _head_update(self, feats, head_in, labels=None):
@@ -118,32 +118,34 @@ class TrainStep:
 
     # ---- software pipeline across steps, eager:   stream G: backbone + ROI pooling of batch k+1   (-> feats_next)
     #                                                stream H: head update of batch k                 (on feats_cur)
-    def _streams(self):
-        if getattr(self, "_sg", None) is None:
-            # both at the default priority: work on streams of different priorities has hung on this platform
-            n_head = self.head_cus
-            if n_head > 0:
-                # disjoint CU sets: the head's small dependent launches do not queue behind the backbone's chip-wide grids
-                import ctypes
-                from ._lib import call
-                total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-                words = (total + 31) // 32
-                hm, bm = (ctypes.c_uint32 * words)(), (ctypes.c_uint32 * words)()
-                # mask bit i is CU i/8 of XCD i%8 on this part: the first n bits take n/8 CUs from every XCD (measured:
-                # 32 CUs taken from ONE XCD instead run 3x slower; 16 / 24 / 28 / 32 / 40 CUs: 7.8k / 8.7k / 8.8k / 9.0k / 8.1k clips/s)
-                for cu in range(total):
-                    (hm if cu < n_head else bm)[cu // 32] |= 1 << (cu % 32)
-                self._raw_streams = []
-                out = []
-                for m in (bm, hm):
-                    h = ctypes.c_void_p()
-                    call("eventad_stream_create_cu_mask", ctypes.cast(m, ctypes.c_void_p), words, ctypes.byref(h))
-                    self._raw_streams.append(h)
-                    out.append(torch.cuda.ExternalStream(h.value))
-                self._sg, self._sh = out
-            else:
+    def _streams(self, masked=False):
+        """The two streams of the pipelined modes, both at the default priority (work on streams of different priorities
+        has hung on this platform).  masked=True: the pair with disjoint CU sets -- `head_cus` CUs for the head's stream,
+        the rest for the backbone's -- so the head's small dependent launches do not queue behind the backbone's
+        chip-wide grids."""
+        if not masked:
+            if getattr(self, "_sg", None) is None:
                 self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream()
-        return self._sg, self._sh
+            return self._sg, self._sh
+        if getattr(self, "_sgm", None) is None:
+            import ctypes
+            from ._lib import call
+            total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            n_head = self.head_cus if self.head_cus > 0 else total // 8
+            words = (total + 31) // 32
+            hm, bm = (ctypes.c_uint32 * words)(), (ctypes.c_uint32 * words)()
+            # mask bit i is CU i/8 of XCD i%8 on this part: the first n bits take n/8 CUs from every XCD (measured at C2:
+            # 32 CUs taken from ONE XCD instead run 3x slower; 16 / 24 / 28 / 32 / 40 CUs: 7.8k / 8.7k / 8.8k / 9.0k / 8.1k clips/s)
+            for cu in range(total):
+                (hm if cu < n_head else bm)[cu // 32] |= 1 << (cu % 32)
+            self._raw_streams, out = [], []
+            for m in (bm, hm):
+                h = ctypes.c_void_p()
+                call("eventad_stream_create_cu_mask", ctypes.cast(m, ctypes.c_void_p), words, ctypes.byref(h))
+                self._raw_streams.append(h)
+                out.append(torch.cuda.ExternalStream(h.value))
+            self._sgm, self._shm = out
+        return self._sgm, self._shm
 
     def prime(self, data):
         """Fill the pipeline: features of the first batch."""
@@ -197,7 +199,6 @@ class TrainStep:
             for _ in range(warmup):
                 self.pipelined_step(in_h[0], None, in_b)
         torch.cuda.current_stream().wait_stream(side)
-        self.restore(snap)
         torch.cuda.synchronize()
         self._pin_workspaces()
         d["gb"], d["gh"], d["feats"], d["out"] = [], [], [], []
@@ -212,8 +213,24 @@ class TrainStep:
         d["ev_b"] = [torch.cuda.Event(), torch.cuda.Event()]
         d["ev_h"] = [torch.cuda.Event(), torch.cuda.Event()]
         d["k"], d["drained"] = 0, False
+        d["masked"] = self.head_cus > 0
+        if self.head_cus < 0:                                  # stand-alone times of the two graphs decide
+            t = []
+            for g_ in (d["gb"][0], d["gh"][0]):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g_.replay()
+                a.record()
+                for _ in range(3):
+                    g_.replay()
+                b.record()
+                torch.cuda.synchronize()
+                t.append(a.elapsed_time(b) / 3)
+            d["graph_ms"] = tuple(t)
+            d["masked"] = t[1] > 0.5 * t[0]
+        self.restore(snap)                                     # warm-up and timing replays were real steps: undone here
+        torch.cuda.synchronize()
         main = torch.cuda.current_stream()
-        sg, sh = self._streams()
+        sg, sh = self._streams(d["masked"])
         sg.wait_stream(main); sh.wait_stream(main)
         with torch.cuda.stream(sg):                            # the first batch enters the pipeline
             d["gb"][0].replay()
@@ -257,7 +274,7 @@ class TrainStep:
         flush() -- or synchronise -- before reading results or re-using the memory of a `next_batch` passed earlier."""
         d = self._dual
         main = torch.cuda.current_stream()
-        sg, sh = self._streams()
+        sg, sh = self._streams(d["masked"])
         if join or next_batch is not None:
             sg.wait_stream(main)                               # next_batch was produced on the caller's stream
         if join:
@@ -285,7 +302,7 @@ class TrainStep:
         The next replay_dual(batch) restarts the pipeline with `batch` (and returns None: no head update in that call)."""
         d = self._dual
         main = torch.cuda.current_stream()
-        sg, sh = self._streams()
+        sg, sh = self._streams(d["masked"])
         sh.wait_stream(main)
         p = d["k"] % 2
         with torch.cuda.stream(sh):

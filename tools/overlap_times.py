@@ -15,7 +15,7 @@ data = format_data(synthetic.make_config_batch(cfg).to(dev))
 ts = TrainStep(model, lr=args.lr, weight_decay=args.weight_decay)
 ts.capture_dual(data)
 d = ts._dual
-sg, sh = ts._streams()
+sg, sh = ts._streams(d["masked"])
 E = lambda: torch.cuda.Event(enable_timing=True)
 def timed(stream, graph, reps=30):
     a, b = E(), E()
@@ -50,4 +50,4 @@ torch.cuda.synchronize()
 h = sum(a.elapsed_time(b) for a, b, _, _ in evs[5:]) / len(evs[5:])
 g = sum(a.elapsed_time(b) for _, _, a, b in evs[5:]) / len(evs[5:])
 step = evs[5][2].elapsed_time(evs[-1][2]) / (len(evs) - 6)
-print("overlapped: backbone graph %.3f ms, head graph %.3f ms, step %.3f ms (head CUs: %d)" % (g, h, step, ts.head_cus))
+print("overlapped: backbone graph %.3f ms, head graph %.3f ms, step %.3f ms (head CUs: %d)" % (g, h, step, (ts.head_cus if ts.head_cus > 0 else 32) if d["masked"] else 0))
