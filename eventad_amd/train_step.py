@@ -145,7 +145,19 @@ class TrainStep:
                 self._raw_streams.append(h)
                 out.append(torch.cuda.ExternalStream(h.value))
             self._sgm, self._shm = out
+            import atexit
+            atexit.register(self.close)                        # HIP streams made outside torch: destroyed before the runtime unloads
         return self._sgm, self._shm
+
+    def close(self):
+        """Destroy the CU-masked streams (idempotent).  Graphs captured by this object must not be replayed afterwards."""
+        raw, self._raw_streams = getattr(self, "_raw_streams", None) or [], []
+        if raw:
+            from ._lib import call
+            torch.cuda.synchronize()
+            self._sgm = self._shm = None
+            for h in raw:
+                call("eventad_stream_destroy", h)
 
     def prime(self, data):
         """Fill the pipeline: features of the first batch."""
