@@ -140,7 +140,7 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
     from eventad_amd.train_step import TrainStep
     W = H = 64; B = 3; n = 3000
     results = []
-    for mode in ("sequential", "pipelined", "graph", "dual", "dual_nojoin"):
+    for mode in ("sequential", "pipelined", "graph", "dual", "dual_nojoin", "dual_masked", "dual_unmasked_nojoin"):
         args, model, sd, head_sd, raw, data = _build(W, H, B, n)
         from dagr.utils.buffers import format_data
         batches = [data] + [format_data(synthetic.make_batch(W, H, n, B, first_clip=3 * k, with_image=False,
@@ -163,8 +163,11 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
                 TrainStep.load_into(buf, b)
                 losses.append(ts.replay()[0].clone())
         else:
-            join = mode == "dual"
+            join = not mode.endswith("nojoin")
+            if "masked" in mode:                             # force / forbid the CU partition (default: decided by timing)
+                ts.head_cus = 32 if mode == "dual_masked" else 0
             ts.capture_dual(batches[0], warmup=2)
+            assert ts._dual["masked"] == (mode == "dual_masked") or "masked" not in mode
             for b in batches[1:]:
                 loss, norm = ts.replay_dual(b, join=join)
                 if join:
@@ -212,3 +215,36 @@ def test_earlier_capture_survives_a_workspace_reallocation():
     for k, v in ts.nh.P.items():
         assert torch.equal(v, got[2][k]), k
     del junk
+
+
+def test_two_graph_pipeline_restarts_after_a_flush_and_closes_its_streams():
+    """flush() drains the pipeline; the next replay_dual(batch) only starts the backbone of `batch` (returns None), the
+    call after it runs that batch's head update.  Two epochs of two batches == four sequential steps, bit for bit.
+    close() destroys the CU-masked streams and may be called twice."""
+    from eventad_amd import synthetic
+    from eventad_amd.train_step import TrainStep
+    from dagr.utils.buffers import format_data
+    W = H = 64; B = 3; n = 3000
+    out = []
+    for mode in ("sequential", "dual"):
+        args, model, sd, head_sd, raw, data = _build(W, H, B, n)
+        other = format_data(synthetic.make_batch(W, H, n, B, first_clip=3, with_image=False, precomputed_feats=True).to("cuda:0"))
+        model.eval()
+        ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
+        if mode == "sequential":
+            for b in (data, other, data, other):
+                ts.step(b)
+        else:
+            ts.head_cus = 32
+            ts.capture_dual(data, warmup=1)
+            ts.replay_dual(other)                            # head(data) || backbone(other)
+            ts.flush()                                       # head(other)
+            assert ts.replay_dual(data) is None              # epoch 2: backbone(data) only
+            ts.replay_dual(other)                            # head(data) || backbone(other)
+            ts.flush()
+            ts.close(); ts.close()
+        torch.cuda.synchronize()
+        out.append(({k: v.clone() for k, v in ts.nh.P.items()}, float(ts.nh.opt_state[0])))
+    assert out[0][1] == out[1][1] == 4.0
+    for k in out[0][0]:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k
