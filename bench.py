@@ -149,6 +149,10 @@ def main():
     from dagr.utils.buffers import format_data
     raw = synthetic.make_config_batch(a.config, first_clip=rank * B)        # each rank owns different clips
     data = format_data(raw.clone().to(dev))
+    if getattr(data, "image_feats", None) is not None:
+        # precomputed CNN feature maps are kept in channels-last memory format ([B,C,h,w] tensors, NHWC in memory): the
+        # layout every sampler kernel reads, so the step has no layout-change launch (plain NCHW maps are accepted too)
+        data.image_feats = [m.contiguous(memory_format=torch.channels_last) for m in data.image_feats]
     model.train()                                                           # as utils/train.py:90 (dropout active)
     ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
     nb = model.dagr_model.backbone._native
@@ -214,7 +218,7 @@ def main():
                        "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
                        "pipeline": ("none" if not pipelined else "backbone(k+1) || head update(k): two graphs on two event-coupled streams"),
                          "cu_partition": ("head graph on %d CUs of its own, backbone graph on the others (CU-masked default-priority streams)" % ((ts.head_cus if ts.head_cus > 0 else torch.cuda.get_device_properties(0).multi_processor_count // 8)) if (pipelined and ts._dual and ts._dual.get("masked")) else "none"),
-                       "input": "device-resident batch, H2D copy excluded; every step runs the full backbone + head update on it",
+                       "input": "device-resident batch, H2D copy excluded; every step runs the full backbone + head update on it; precomputed feature maps stored channels-last (NHWC in memory)",
                        "skipped_vs_reference": "ROI pooling of the previous-frame boxes (computed by the reference, never read by its forward)",
                        "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
                        "final_loss": round(float(loss), 4)},

@@ -232,21 +232,36 @@ class NativeBackbone:
         pos = pos.contiguous().float()
         polarity = polarity.reshape(-1).contiguous().float()
         batch = batch.contiguous().long()
+        # The kernels read the CNN maps as NHWC.  Maps that already are -- the live trunk's output (feats_are_nhwc), or
+        # [B,C,h,w] tensors in torch's channels_last memory format, e.g. precomputed features stored that way -- are used
+        # in place; plain NCHW maps go through one grouped layout-change launch (maps 2..4 straight into the hand-off set).
         maps, todo = [], []
+        in_place = True
         for i, m in enumerate(image_feats):
-            m = m.contiguous().float()
-            dst = hand.maps[i - 2] if i >= 2 else None     # maps 2..4 travel with the hand-off
+            m = m.float()
+            if not feats_are_nhwc and m.dim() == 4 and m.is_contiguous(memory_format=torch.channels_last) and m.shape[1] > 1:
+                maps.append(m.permute(0, 2, 3, 1))           # a contiguous NHWC view of the same memory
+                continue
+            m = m.contiguous()
             if feats_are_nhwc:
-                if dst is not None:
-                    dst.copy_(m)
-                maps.append(dst if dst is not None else m)
-            else:
-                if dst is not None:
-                    assert tuple(dst.shape) == (m.shape[0], m.shape[2], m.shape[3], m.shape[1]), "unexpected CNN map size"
-                o = dst if dst is not None else torch.empty((m.shape[0], m.shape[2], m.shape[3], m.shape[1]),
-                                                            dtype=torch.float32, device=m.device)
-                todo.append((m, o))
-                maps.append(o)
+                maps.append(m)
+                continue
+            in_place = False
+            dst = hand.maps[i - 2] if i >= 2 else None
+            if dst is not None:
+                assert tuple(dst.shape) == (m.shape[0], m.shape[2], m.shape[3], m.shape[1]), "unexpected CNN map size"
+            o = dst if dst is not None else torch.empty((m.shape[0], m.shape[2], m.shape[3], m.shape[1]),
+                                                        dtype=torch.float32, device=m.device)
+            todo.append((m, o))
+            maps.append(o)
+        assert all(m.is_contiguous() for m in maps)
+        # maps 2..4 feed the pooled stage: tail() on this pass's hand-off set reads them where they are
+        self._tail_maps = maps[2:] if in_place else None
+        if not in_place:
+            for i in range(2, 5):                            # mixed input: make the hand-off set complete
+                if maps[i].data_ptr() != hand.maps[i - 2].data_ptr():
+                    hand.maps[i - 2].copy_(maps[i])
+                    maps[i] = hand.maps[i - 2]
         if todo:                                            # every NCHW -> NHWC layout change of the step in one launch
             d = (ctypes.c_int64 * (6 * len(todo)))()
             for i, (m, o) in enumerate(todo):
@@ -309,6 +324,8 @@ class NativeBackbone:
         B = self._B
         levels = ws["levels"]
         L0 = levels[0]
+        own = hand is ws["hand"][0] and getattr(self, "_tail_maps", None) is not None
+        tail_maps = self._tail_maps if own else hand.maps       # NHWC inputs of this pass are read in place
         # level-0 graph arrays come from the hand-off; everything this stage writes for level 0 is its own
         G0 = Level()
         G0.__dict__.update(L0.__dict__)
@@ -326,7 +343,7 @@ class NativeBackbone:
                 Lp = view[lv - 1]
                 vsx, vsy = g.voxel[lv]
                 mean = 1 if g.pool_aggr[lv] == "mean" else 0
-                fmap = hand.maps[lv - 1]
+                fmap = tail_maps[lv - 1]
                 self._c("eventad_pool_scatter", _rp(Lp.y), 64, 64, _rp(fmap), fmap.shape[1], fmap.shape[2], 64,
                      _rp(Lp.npos), _rp(Lp.npix), _rp(Lp.nbatch), None, None, Lp.n_max, _rp(Lp.n_dev), g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),

@@ -218,3 +218,29 @@ def test_rarely_taken_kernel_paths_give_the_same_results():
     e = edges.cpu()
     want = G.build_edges(data.pos, data.batch, W, H, 1000000, B, 0.01, K)
     assert torch.equal(e[:, e[1] >= 0], want)
+
+
+def test_channels_last_feature_maps_are_used_in_place():
+    """[B,C,h,w] maps in torch's channels_last memory format are NHWC in memory: the backbone reads them without the
+    layout-change launch and must give exactly what it gives for plain NCHW maps of the same values."""
+    import torch
+    from oracle import dagr_ref
+    from eventad_amd import synthetic, weights
+    from eventad_amd.backbone import NativeBackbone
+    dev = torch.device("cuda:0")
+    W = H = 64; B = 3; n = 4000
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True))
+    sd = weights.random_graph_state()
+    outs = []
+    for fmt in ("nchw", "channels_last"):
+        nb = NativeBackbone(sd, W, H, dev)
+        maps = [m.to(dev) for m in data.image_feats]
+        if fmt == "channels_last":
+            maps = [m.contiguous(memory_format=torch.channels_last) for m in maps]
+        nb.timing = {}
+        res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, maps)
+        torch.cuda.synchronize()
+        assert ("eventad_nchw_to_nhwc_group#1" in nb.timing) == (fmt == "nchw")
+        n4, n3 = int(res["out4"]["n_dev"].item()), int(res["out3"]["n_dev"].item())
+        outs.append((res["out4"]["x"][:n4].clone(), res["out3"]["x"][:n3].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
