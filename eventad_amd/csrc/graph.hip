@@ -834,6 +834,176 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pixel-centric edge search for dense input (several events per pixel: C3, C5).
+// All events of one pixel walk the SAME neighbour pixels in the same order; they differ only in their own id and time.
+// The per-event walks above load every neighbour pixel's bounds and FIFO entries once per destination EVENT, one
+// dependent round trip at a time, and a wave waits for the longest walk of its 64 lanes.  Here one wave (= one
+// workgroup) owns one destination PIXEL.  A pass covers GS consecutive spiral steps: lane l of each of the 64/GS lane
+// groups holds, in registers, the bounds and the PIX_DEPTH newest FIFO entries of step i0 + l (two round trips per
+// pass), and the groups then go through the pixel's unfinished events, 64/GS at a time, one event per group.  For its
+// event a lane counts, among its entries, those not older than the event (ids ascend inside a segment, so they are the
+// newest `nnew`) and those that pass the reference's tests (older id, dt <= delta_t; with timestamps that do not
+// decrease with the id they are the next `nq`); the exclusive sum of nq over the lower lanes of the group -- spiral
+// order -- is where the lane's sources go in the row, newest first, until 16 slots are taken: the reference's row.
+// A lane whose registers do not decide a deep pixel (all PIX_DEPTH entries newer or taken) reads on from memory.
+// The first pass runs with 64/GS1 groups of GS1 steps (16 at five or more events per pixel, else 32: most events are
+// done after that many pixels); the events that still have fewer than 16 sources -- the early ones of the clip -- go on
+// alone with 64 steps per pass.
+// Rows are assembled in LDS and written as whole lines.  Batches whose timestamps are not monotone take an exact
+// per-event walk (the `continue` of the reference matters then).
+#define PIX_DEPTH 8
+template <int GS, bool INT_CMP>
+__device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int N, int W, int H,
+                                             int steps, int Q, int dt_max, int x, int y, int plane_base, int i0, int md,
+                                             int* my_src, unsigned short* my_stp, const int2* my_dest, int* my_cnt) {
+    constexpr int MAXNB = 16, NG = 64 / GS;
+    const int lane = threadIdx.x & 63, g = lane / GS, l = lane % GS;
+    const int gshift = g * GS;
+    const unsigned long long gmask = GS == 64 ? ~0ull : ((1ull << GS) - 1ull);
+    const unsigned long long below = (1ull << l) - 1ull;
+    const float fdt = (float)dt_max;
+    const int i = i0 + l;
+    const int ii = min(i, steps - 1);
+    const int xn = x + c_spiral[2 * ii], yn = y + c_spiral[2 * ii + 1];
+    const bool ok = i < steps && xn >= 0 && yn >= 0 && xn < W && yn < H;
+    const int q = ok ? plane_base + xn + W * yn : 0;
+    const int st = (int)start[q], en = (int)start[q + 1];
+    const int lo = ok ? max(st, en - Q) : en;                // the FIFO keeps only the newest Q ids
+    const int len = en - lo, lenr = min(len, PIX_DEPTH), ninv = PIX_DEPTH - lenr;
+    int eid[PIX_DEPTH], et[PIX_DEPTH];
+#pragma unroll
+    for (int v = 0; v < PIX_DEPTH; ++v) {
+        const int2 c = ev2[min(max(en - 1 - v, lo), N - 1)];
+        eid[v] = v < lenr ? c.x : 0x7fffffff;                // padding counts as "not older" and is subtracted again (ninv)
+        et[v] = c.y;
+    }
+    // oldest entry of a deep pixel: if even that one is not older than the event, nothing below the registers is
+    const int eold = len > PIX_DEPTH ? ev2[min(lo, N - 1)].x : 0x7fffffff;
+    unsigned long long todo = __ballot(my_cnt[lane] < MAXNB);            // bit d: event d still lacks sources
+    while (todo) {
+        int d;                                               // this group's event: the g-th lowest set bit (NG == 1: the lowest)
+        bool act = true;
+        if (NG == 1) { d = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+        else {
+            unsigned long long t = todo;
+            for (int k = 0; k < g; ++k) t &= t - 1;
+            act = t != 0;
+            d = act ? __ffsll((long long)t) - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) todo &= todo - 1;   // (clearing a bit of 0 leaves 0)
+        }
+        const int base = my_cnt[d];
+        const int2 mine = my_dest[d];
+        const int me = mine.x, ts = mine.y;
+        int cge = 0, nq = 0;
+#pragma unroll
+        for (int v = 0; v < PIX_DEPTH; ++v) {
+            const bool older = eid[v] < me;
+            const int dt = ts - et[v];
+            // (float)(ts - t) > (float)delta_t  <=>  ts - t > delta_t  whenever |delta_t| + 1 is exactly representable
+            const bool far = INT_CMP ? dt > dt_max : (float)dt > fdt;
+            cge += older ? 0 : 1;
+            nq += (older && !far) ? 1 : 0;
+        }
+        int nnew = cge - ninv;
+        if (!act) nq = 0;
+        if (act && eold < me && nnew + nq == PIX_DEPTH) {                // deep pixel, registers undecided: read on
+            for (int s = en - 1 - PIX_DEPTH; s >= lo && nq < MAXNB; --s) {
+                const int2 c = ev2[s];
+                if (c.x >= me) { ++nnew; continue; }
+                const int dt = ts - c.y;
+                if (INT_CMP ? dt > dt_max : (float)dt > fdt) break;
+                ++nq;
+            }
+        }
+        // exclusive sum of nq over the lower lanes of the group and its total: one ballot per level of nq
+        int off = 0, tot = 0;
+        for (int k = 0; k < MAXNB; ++k) {
+            const unsigned long long m = __ballot(nq > k);
+            if (!m) break;
+            const unsigned long long mg = (m >> gshift) & gmask;
+            off += __popcll(mg & below); tot += __popcll(mg);
+        }
+        const int take = min(nq, MAXNB - base - off);        // slots left for this lane's sources
+        for (int k = 0; k < take; ++k) {
+            my_src[d * MAXNB + base + off + k] = en - 1 - nnew - k;
+            my_stp[d * MAXNB + base + off + k] = (unsigned short)i;
+        }
+        if (l == 0 && act) my_cnt[d] = min(MAXNB, base + tot);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS written by one lane, read by others of the wave
+}
+
+template <int GS1, bool INT_CMP>
+__global__ __launch_bounds__(64) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
+                                                      const unsigned* __restrict__ flags_in, int N, int P, int W, int H, int steps,
+                                                      int Q, int dt_max, int* __restrict__ ell_src,
+                                                      uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
+    constexpr int MAXNB = 16;
+    __shared__ int my_src[64 * MAXNB];
+    __shared__ unsigned short my_stp[64 * MAXNB];
+    __shared__ int2 my_dest[64];
+    __shared__ int my_cnt[64];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
+    const int ds = __builtin_amdgcn_readfirstlane((int)start[p]), de = __builtin_amdgcn_readfirstlane((int)start[p + 1]);
+    if (de <= ds) return;
+    const int x = p % W, y = (p / W) % H, plane_base = p - x - W * y;
+    if (flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE) {            // rare: plain per-event walk, rows written slot by slot
+        for (int r = ds + lane; r < de; r += 64) {
+            const int2 mine = ev2[r];
+            int* row = ell_src + (size_t)r * MAXNB;
+            uint16_t* srow = ell_step + (size_t)r * MAXNB;
+            for (int e = 1; e < MAXNB; ++e) { row[e] = 0; srow[e] = 0; }
+            row[0] = r; srow[0] = 0;
+            int nn = 1;
+            for (int i = 0; i < steps && nn < MAXNB; ++i) {
+                const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+                if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
+                const int q = plane_base + xn + W * yn;
+                const int st = (int)start[q], en = (int)start[q + 1];
+                const int lo = max(st, en - Q);
+                for (int s = en - 1; s >= lo; --s) {
+                    const int2 c = ev2[s];
+                    if (mine.x > c.x) {
+                        if ((float)(mine.y - c.y) > (float)dt_max) continue;
+                        row[nn] = s; srow[nn] = (uint16_t)i;
+                        if (++nn >= MAXNB) break;
+                    }
+                }
+            }
+            deg[r] = nn;
+        }
+        return;
+    }
+    for (int d0 = ds; d0 < de; d0 += 64) {                   // the pixel's destination events, 64 at a time
+        const int md = min(64, de - d0);
+        my_dest[lane] = ev2[min(d0 + lane, N - 1)];
+        my_cnt[lane] = lane < md ? 1 : MAXNB;                // sources found so far for event d0 + lane (self edge first)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ((int4*)my_src)[j * 64 + lane] = make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ((uint4*)my_stp)[j * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+        my_src[lane * MAXNB] = d0 + lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int first = min(GS1, steps);
+        ell_pix_pass<GS1, INT_CMP>(ev2, start, N, W, H, first, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt);
+        for (int i0 = first; i0 < steps; i0 += 64) {
+            if (!__ballot(my_cnt[lane] < MAXNB)) break;
+            ell_pix_pass<64, INT_CMP>(ev2, start, N, W, H, steps, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j * 64 + lane < md * 4) ((int4*)(ell_src + (size_t)d0 * MAXNB))[j * 64 + lane] = ((const int4*)my_src)[j * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j * 64 + lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[j * 64 + lane] = ((const uint4*)my_stp)[j * 64 + lane];
+        if (lane < md) deg[d0 + lane] = my_cnt[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                                  const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,
                                  int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
@@ -857,8 +1027,18 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         if (radius_px == 1) { if (bitmap) EVAD_RS(1, true); else EVAD_RS(1, false); }
         else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
 #undef EVAD_RS
+    } else if (fast && !bitmap && (variant == 2 || (variant == 0 && (double)N >= 2.0 * (double)B * W * H))) {
+        const long long P = (long long)B * W * H;            // dense input (>= 2 events per pixel on average): wave per pixel
+        if (P > 0x7fffffffLL) return EVAD_ERR_ARG;
+        const bool int_cmp = delta_t_us > -(1 << 24) + 1 && delta_t_us < (1 << 24) - 1;
+        const bool very_dense = (double)N >= 5.0 * (double)P;
+#define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC>), dim3((unsigned)P), dim3(64), 0, st, (const int2*)ev2, pix_start, \
+                                            counters, N, (int)P, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg)
+        if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
+        else            { if (int_cmp) EVAD_PIX(32, true); else EVAD_PIX(32, false); }
+#undef EVAD_PIX
     } else if (fast) {
-        const bool by_rank = (double)N >= 2.0 * (double)B * W * H;          // >= 2 events per pixel on average
+        const bool by_rank = (double)N >= 2.0 * (double)B * W * H;          // (variant 3 keeps this walk for dense input)
         const int threads = by_rank ? ELL_TILE : 256;
         const dim3 tgrid(evad_blocks(N, threads));
 #define EVAD_REG(MK, BR) hipLaunchKernelGGL((k_build_ell_reg<MK, BR>), tgrid, dim3(threads), 0, st, (const int2*)ev2, key_s, pix_start, \

@@ -96,9 +96,12 @@ int eventad_sort_events_static(const float* pos, const int64_t* batch, const flo
  * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
  * the source-voxel bit in the destination voxel's pool1 neighbour bitmap u32[S,3] (= eventad_pool_edges_mark_ell).
  * variant (needs ev2 and max_num_neighbors == 16, else the reference-style walk runs and bitmap must be NULL):
- * 0 = thread per event walking the spiral with the row in registers and an early exit after 16 neighbours (dense
- * windows); 1 = row scan, radius 1 or 3 only (2R+1 contiguous range look-ups per event instead of (2R+1)^2 pixel
- * probes, candidates fetched 8 at a time -- sparse windows; other radii fall back to 0).  Identical rows either way.
+ * 0 = by density: with two or more events per pixel on average and no bitmap, one wave per destination PIXEL (lanes =
+ * spiral steps, the neighbour pixels' newest entries held in registers and shared by all events of the pixel);
+ * otherwise thread per event walking the spiral with the row in registers and an early exit after 16 neighbours;
+ * 1 = row scan, radius 1 or 3 only (2R+1 contiguous range look-ups per event instead of (2R+1)^2 pixel
+ * probes, candidates fetched 8 at a time -- sparse windows; other radii fall back to 0); 2 = wave per pixel whatever the
+ * density (bitmap must be NULL, else as 3); 3 = thread per event whatever the density.  Identical rows in every case.
  * bitmap_prezeroed != 0: the caller already cleared the bitmap. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,

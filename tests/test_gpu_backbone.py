@@ -8,7 +8,7 @@ from eventad_amd._lib import call, ptr
 pytestmark = pytest.mark.gpu
 
 
-def _setup(W, H, n, B, t_span_us=50000, mode="gather"):
+def _setup(W, H, n, B, t_span_us=50000, mode="gather", ell_variant=None):
     from oracle import dagr_ref
     from eventad_amd.backbone import NativeBackbone
     data = synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True, t_span_us=t_span_us)
@@ -18,6 +18,8 @@ def _setup(W, H, n, B, t_span_us=50000, mode="gather"):
     (o3, o4), stages = dagr_ref.backbone_forward(sd, data, cfg, data.image_feats, return_all=True, mode=mode)
     dev = torch.device("cuda:0")
     nb = NativeBackbone(sd, W, H, dev)
+    if ell_variant is not None:
+        nb.ell_variant = ell_variant
     res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
     torch.cuda.synchronize()
     assert nb.check_flags() & ~1 == 0
@@ -52,9 +54,12 @@ def test_backbone_matches_oracle(W, H, n, B, span):
 BIG_CASES = [(640, 480, 60000, 2, 12000), (640, 480, 20000, 2, 50000), (1280, 720, 80000, 2, 12000), (1280, 720, 12000, 3, 50000)]
 
 
+# ell_variant 2 forces the wave-per-pixel edge search (the default at two or more events per pixel) on these sparse
+# inputs: 4 and 12 passes of 64 spiral steps, mostly empty neighbour pixels
+@pytest.mark.parametrize("ell_variant", [None, 2])
 @pytest.mark.parametrize("W,H,n,B,span", BIG_CASES)
-def test_backbone_matches_oracle_large_sensors(W, H, n, B, span):
-    data, cfg, outs, stages, nb, res = _setup(W, H, n, B, span, mode="ondemand")
+def test_backbone_matches_oracle_large_sensors(W, H, n, B, span, ell_variant):
+    data, cfg, outs, stages, nb, res = _setup(W, H, n, B, span, mode="ondemand", ell_variant=ell_variant)
     deg = res["ws"]["deg"][: data.pos.shape[0]]
     if span <= 12000:
         assert float((deg == 16).float().mean()) > 0.3          # the neighbour cap really binds
@@ -149,9 +154,42 @@ def test_gemm_matches_torch():
         assert torch.allclose(C, ref, atol=1e-4, rtol=1e-4)
 
 
+def _ell_rows(nb, data, B, dev):
+    res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    torch.cuda.synchronize()
+    ws = res["ws"]
+    N = data.pos.shape[0]
+    live = torch.arange(16, device=dev).view(1, -1) < ws["deg"][:N].view(-1, 1)
+    return ws["deg"][:N].clone(), torch.where(live, ws["ell_src"][:N], -1), torch.where(live, ws["ell_step"][:N].int(), -1)
+
+
+def test_wave_per_pixel_edge_search_equals_the_walk_on_dense_input():
+    """640x480 (search radius 7: 225 spiral steps = 4 passes of 64) at 4.9 events per pixel, a third of the pixels deeper
+    than the 8 entries a lane keeps in registers, plus one pixel with 300 events (more than 64 destinations, deeper than
+    the FIFO): the wave-per-pixel search (what this density gets by default) and the per-event walk (compared with the
+    oracle in the tests above) give identical rows."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    W, H, B = 640, 480, 1
+    raw = synthetic.make_batch(W, H, 1500000, B, with_image=False, precomputed_feats=True)
+    raw.pos[1000:1300] = torch.tensor([100, 50], dtype=raw.pos.dtype)
+    data = dagr_ref.format_data(raw)
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
+    outs = []
+    for variant in (3, None, 2):
+        nb.ell_variant = variant
+        outs.append(_ell_rows(nb, data, B, dev))
+    assert int((outs[0][0] < 16).sum()) > 1000 and float((outs[0][0] == 16).float().mean()) > 0.5
+    assert int(outs[0][2].max()) > 64                            # sources beyond the first pass of 64 steps
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+
+
 def test_both_edge_search_kernels_give_the_same_rows():
-    """Row scan (sparse windows) and register-row spiral walk (dense windows) on the same batch: identical ELL rows,
-    degrees, pooled graph -- whichever the occupancy heuristic would pick."""
+    """Row scan (sparse windows), register-row spiral walk (dense windows) and wave-per-pixel search (dense input) on the
+    same batch: identical ELL rows, degrees, pooled graph -- whichever the occupancy heuristic would pick."""
     from oracle import dagr_ref
     from eventad_amd.backbone import NativeBackbone
     W = H = 256
@@ -159,7 +197,7 @@ def test_both_edge_search_kernels_give_the_same_rows():
     data = dagr_ref.format_data(data)
     dev = torch.device("cuda:0")
     outs = []
-    for variant in (0, 1):
+    for variant in (0, 1, 2, 3):
         nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
         nb.ell_variant = variant
         res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), 3, [m.to(dev) for m in data.image_feats])
@@ -170,8 +208,9 @@ def test_both_edge_search_kernels_give_the_same_rows():
         n, e = int(L.n_dev.item()), int(L.e_dev.item())
         outs.append((ws["deg"].clone(), torch.where(live, ws["ell_src"], -1), torch.where(live, ws["ell_step"].int(), -1),
                      L.csr_src[:e].clone(), L.rowptr[: n + 1].clone(), res["out4"]["x"][: int(res["out4"]["n_dev"].item())].clone()))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
 
 
 def test_pooled_positions_at_full_density_and_non_power_of_two_width():

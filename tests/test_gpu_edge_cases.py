@@ -11,7 +11,7 @@ from eventad_amd._lib import call, ptr
 pytestmark = pytest.mark.gpu
 
 
-def _run(raw, W, H, B):
+def _run(raw, W, H, B, ell_variant=None):
     from oracle import dagr_ref
     from eventad_amd.backbone import NativeBackbone
     data = dagr_ref.format_data(raw.clone())
@@ -19,6 +19,8 @@ def _run(raw, W, H, B):
     (o3, o4), stages = dagr_ref.backbone_forward(sd, data, dagr_ref.make_config(W, H, B), data.image_feats, return_all=True)
     dev = torch.device("cuda:0")
     nb = NativeBackbone(sd, W, H, dev)
+    if ell_variant is not None:
+        nb.ell_variant = ell_variant
     res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
     torch.cuda.synchronize()
     flags = nb.check_flags()
@@ -44,29 +46,36 @@ def _clips(W, H, ns, **kw):
     return [synthetic.make_clip(i, W, H, n, with_image=False, precomputed_feats=True, **kw) for i, n in enumerate(ns)]
 
 
-def test_ragged_clips_and_an_empty_clip():
+# ell_variant: None = the edge search the density heuristic picks, 2 = the wave-per-pixel search forced
+VARIANTS = [None, 2]
+
+
+@pytest.mark.parametrize("ell_variant", VARIANTS)
+def test_ragged_clips_and_an_empty_clip(ell_variant):
     W = H = 64
     raw = EventBatch.from_clips(_clips(W, H, [1500, 0, 4000, 7]))
-    _run(raw, W, H, 4)
+    _run(raw, W, H, 4, ell_variant)
 
 
-def test_hot_pixel_exceeds_fifo_depth():
+@pytest.mark.parametrize("ell_variant", VARIANTS)
+def test_hot_pixel_exceeds_fifo_depth(ell_variant):
     W = H = 64
     clips = _clips(W, H, [3000, 2500])
     clips[0]["pos"][500:900] = torch.tensor([10, 20], dtype=torch.int16)        # 400 events in one pixel (> Q = 128)
     clips[1]["pos"][::3] = torch.tensor([5, 5], dtype=torch.int16)              # ~830 events in one pixel
-    flags, res, stages = _run(EventBatch.from_clips(clips), W, H, 2)
+    flags, res, stages = _run(EventBatch.from_clips(clips), W, H, 2, ell_variant)
     assert int(res["ws"]["counters"][3].item()) >= 800                          # longest pixel segment, far beyond the FIFO depth
 
 
-def test_non_monotone_timestamps_take_the_exact_scan_path():
+@pytest.mark.parametrize("ell_variant", VARIANTS)
+def test_non_monotone_timestamps_take_the_exact_scan_path(ell_variant):
     W = H = 64
     clips = _clips(W, H, [2500, 2500], t_span_us=30000)
     g = torch.Generator().manual_seed(9)
     for c in clips:
         perm = torch.randperm(2500, generator=g)
         c["t"] = c["t"][perm].contiguous()                                      # ids no longer ordered by time
-    flags, _, _ = _run(EventBatch.from_clips(clips), W, H, 2)
+    flags, _, _ = _run(EventBatch.from_clips(clips), W, H, 2, ell_variant)
     assert flags & 1                                                            # EVENTAD_FLAG_T_NOT_MONOTONE raised
 
 
