@@ -40,6 +40,9 @@ class NativeBackbone:
         self.device = torch.device(device)
         self.prefix = prefix
         self._ws_key = None
+        self.ws = None
+        self._front_zero_words = None
+        self._slot, self._slots = 0, {}             # workspace sets (select_workspace): passes that overlap in time use different ones
         self.keep_superseded_workspaces = False     # set once a hipGraph holds raw pointers into the workspace: a workspace
         self._retired_ws = []                       # that has to grow is then retired (kept alive) instead of freed
         # edge-search kernel: -1 = thread per event, ELL row in registers (fastest on C2: 130 us); >0 = LDS-staged strips of
@@ -195,6 +198,16 @@ class NativeBackbone:
         ws["levels"] = levels
         self.ws, self._ws_key = ws, (N, B)
         return ws
+
+    def select_workspace(self, slot):
+        """Every following pass runs in workspace set `slot` (allocated on first use).  Two passes may overlap in time --
+        on different streams, e.g. the backbone graphs of consecutive batches in TrainStep -- only if they were issued under
+        different sets; weights are shared."""
+        if slot == self._slot:
+            return
+        self._slots[self._slot] = (self.ws, self._ws_key, self._front_zero_words)
+        self.ws, self._ws_key, self._front_zero_words = self._slots.get(slot, (None, None, None))
+        self._slot = slot
 
     def _c(self, name, *args):
         if self.timing is None:

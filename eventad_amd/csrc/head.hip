@@ -24,7 +24,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (__expf(2.
 // (clip, track) lookup tables: replaces EventAD.py:229-255 (first matching box row, normalised box,
 // label) and gathers the current-frame ROI features into the GEMM operand X[B*32, 64].
 __global__ void k_head_tables(const float* __restrict__ bbox, const long long* __restrict__ bbox_batch, int M,
-                              const float* __restrict__ labels, const float* __restrict__ feats, int B, float Wimg,
+                              const float* __restrict__ labels, int label_col, const float* __restrict__ feats, int B, float Wimg,
                               float Himg, float* __restrict__ X, float* __restrict__ CO, int* __restrict__ target,
                               int* __restrict__ valid) {
     int row = blockIdx.x, b = row / NT, k = row % NT, j = threadIdx.x;      // 64 threads = 64 channels
@@ -47,7 +47,7 @@ __global__ void k_head_tables(const float* __restrict__ bbox, const long long* _
             const float* bb = bbox + (size_t)found * 6;
             c0 = (float)((double)bb[0] / (double)Wimg); c1 = (float)((double)bb[1] / (double)Himg);
             c2 = (float)((double)bb[2] / (double)Wimg); c3 = (float)((double)bb[3] / (double)Himg);
-            t = labels ? (int)labels[found] : 0;
+            t = labels ? (int)labels[found] : (label_col >= 0 ? (int)bb[label_col] : 0);
         }
         CO[(size_t)row * 4] = c0; CO[(size_t)row * 4 + 1] = c1; CO[(size_t)row * 4 + 2] = c2; CO[(size_t)row * 4 + 3] = c3;
         target[row] = t;
@@ -55,12 +55,12 @@ __global__ void k_head_tables(const float* __restrict__ bbox, const long long* _
     }
 }
 
-extern "C" int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, const float* labels,
+extern "C" int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, const float* labels, int label_col,
                                    const float* feats, int B, int width, int height, float* X, float* CO,
                                    int32_t* target, int32_t* valid, void* stream) {
-    if (!feats || !X || !CO || !target || !valid || B <= 0 || M < 0 || (M > 0 && (!bbox || !bbox_batch))) return EVAD_ERR_ARG;
+    if (!feats || !X || !CO || !target || !valid || B <= 0 || M < 0 || (M > 0 && (!bbox || !bbox_batch)) || label_col > 5) return EVAD_ERR_ARG;
     hipLaunchKernelGGL(k_head_tables, dim3(B * NT), dim3(64), 0, (hipStream_t)stream, bbox, (const long long*)bbox_batch, M,
-                       labels, feats, B, (float)width, (float)height, X, CO, target, valid);
+                       labels, label_col, feats, B, (float)width, (float)height, X, CO, target, valid);
     return evad_last_error();
 }
 
@@ -406,10 +406,13 @@ __global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void k_opt_prepare(const float* __restrict__ partial, float max_norm, double beta1, double beta2, float* __restrict__ state) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float s = 0.f;
-    for (int i = 0; i < NORM_BLOCKS; ++i) s += partial[i];
+__global__ __launch_bounds__(64) void k_opt_prepare(const float* __restrict__ partial, float max_norm, double beta1, double beta2, float* __restrict__ state) {
+    // 256 partial sums: 4 per lane (independent loads), then a fixed shuffle tree -- reproducible
+    const int lane = threadIdx.x;
+    float s = (partial[lane] + partial[64 + lane]) + (partial[128 + lane] + partial[192 + lane]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane != 0) return;
     float norm = sqrtf(s);
     state[1] = norm;
     // The reference raises on a non-finite gradient BEFORE optimizer.step() (utils/train.py:144-149), so its weights

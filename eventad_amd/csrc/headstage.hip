@@ -1,0 +1,275 @@
+// eventad_amd/csrc/headstage.hip -- one launch per clip stage of the EventAD head's forward recurrence.
+//
+// Reference: the per-clip, per-track loop of EventADModel.forward (models/EventAD.py:211-323): GRU(64->256, 2 layers)
+// and GRU(4->32) cells on the tracks of a clip, then SpatialAttention over the clip's valid tracks, whose output is the
+// hidden state handed to the next clip (:320-323).
+//
+// The chain of B clips is pure dependent latency.  As separate launches a stage is a grouped GEMM (state . Whh^T, many
+// workgroups) followed by a one-workgroup cell + attention kernel (the attention is a reduction over whole rows), i.e.
+// two dependent launches per clip.  Here a stage is ONE launch of 32 workgroups: workgroup g owns hidden columns
+// 8g .. 8g+7 of the two 256-wide GRU layers and column g of the 32-wide coordinate GRU, and
+//   A. recomputes the attention of the PREVIOUS clip from that clip's cell outputs (every workgroup does the whole
+//      32 x 256 reduction redundantly: 8 tanh per thread) and so obtains the state entering this clip, as the A operand
+//      of its products, in LDS;
+//   B. multiplies it with its 24 gate rows of Whh (fp32 MFMA 32x32x2, K split over 4 waves, partial sums added in wave
+//      order: reproducible) -- for layer 1 also the input product with the dropout'd layer-0 output;
+//   C. applies the GRU cell to its columns and writes gates, new hidden columns and the state columns it owns.
+// The wavefront of head_native.py is kept: a stage runs layer 0 and the coordinate GRU on clip b and layer 1 on clip b-1.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NT 32                   // track slots per clip
+#define HS_LD 260               // LDS row stride (floats) of a 32 x 256 operand tile: 16-byte aligned rows
+#define HS_WGS 32               // workgroups per stage = 256 / 8 hidden columns = the 32 columns of the coordinate GRU
+
+// same forms as head.hip (v_exp_f32 based; saturate correctly)
+__device__ __forceinline__ float hs_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float hs_tanh(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
+
+struct HsSlot {
+    const float* hn_prev; const float* s_prev; const int* valid_prev; const float* w_att; float* alpha_prev; float* s_cur;
+    const float* whh; const float* bhh; const float* gi; const float* xin; const float* wih; const float* bih;
+    float* gh_out; float* gates; float* hn; const float* mask; float* xdrop; int present;
+};
+struct HsGroup { HsSlot s[3]; };     // [0] 256-wide, input product precomputed; [1] 256-wide, input product xin . Wih^T here; [2] 32-wide
+
+#define HS_SMEM_FLOATS (3 * NT * HS_LD + NT * 36 + 9 * NT + 13 * NT * 24)
+
+__global__ __launch_bounds__(1024) void k_head_stage_fwd(HsGroup G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*sA)[NT][HS_LD] = (float (*)[NT][HS_LD])smem;                  // [0] state of slot 0, [1] state of slot 1, [2] xin of slot 1
+    float (*sC)[36] = (float (*)[36])(smem + 3 * NT * HS_LD);             // state of slot 2 (32 x 32)
+    float* s_part = smem + 3 * NT * HS_LD + NT * 36;                      // [3][32] attention scores
+    float* s_al = s_part + 3 * NT;                                        // [3][32] attention weights
+    int* s_v = (int*)(s_al + 3 * NT);                                     // [3][32] validity of the previous clip's tracks
+    float (*Red)[NT][24] = (float (*)[NT][24])(s_al + 6 * NT);            // [13][32][24] partial products of the 13 MFMA waves
+    const int tid = threadIdx.x, k = tid >> 5, c = tid & 31, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+    const HsSlot& S0 = G.s[0]; const HsSlot& S1 = G.s[1]; const HsSlot& S2 = G.s[2];
+    const bool a0 = S0.present && S0.hn_prev, a1 = S1.present && S1.hn_prev, a2 = S2.present && S2.hn_prev;
+
+    // ---- every global operand of the stage is requested up front (one round trip instead of one per phase): the previous
+    //      clip's cell outputs, the states kept for invalid tracks, layer 1's input rows, and each MFMA wave's weight rows
+    const int nn = lane & 31, h = lane >> 5;
+    float4 bw[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool mf_live = wave < 4 ? S0.present != 0 : (wave < 12 ? S1.present != 0 : (wave == 12 && S2.present != 0));
+    if (mf_live && wave < 12 && nn < 24) {
+        const float* Wm = wave < 4 ? S0.whh : (wave < 8 ? S1.whh : S1.wih);
+        const int n = (nn >> 3) * 256 + 8 * g + (nn & 7);                // gate row (r | z | n blocks of 256) of lane nn < 24
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bw[t] = *(const float4*)(Wm + (size_t)n * 256 + (wave & 3) * 64 + 8 * t + 4 * h);
+    } else if (mf_live && wave == 12 && nn < 3) {                          // coordinate GRU: K = 32, gate rows g, 32 + g, 64 + g
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bw[t] = *(const float4*)(S2.whh + (size_t)(nn * 32 + g) * 32 + 8 * t + 4 * h);
+    }
+    float hn0[8], hn1[8], kp0[8], kp1[8], xin[8], hnc = 0.f, kpc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { hn0[i] = 0.f; hn1[i] = 0.f; kp0[i] = 0.f; kp1[i] = 0.f; xin[i] = 0.f; }
+    if (S0.present) {
+        const float* keep = a0 ? S0.s_prev : S0.s_cur;       // no previous clip: the initial state, stored in this clip's rows
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int j = c + 32 * i; if (a0) hn0[i] = S0.hn_prev[k * 256 + j]; kp0[i] = keep[k * 256 + j]; }
+    }
+    if (S1.present) {
+        const float* keep = a1 ? S1.s_prev : S1.s_cur;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = c + 32 * i;
+            if (a1) hn1[i] = S1.hn_prev[k * 256 + j];
+            kp1[i] = keep[k * 256 + j]; xin[i] = S1.xin[k * 256 + j];
+        }
+    }
+    if (S2.present) { if (a2) hnc = S2.hn_prev[k * 32 + c]; kpc = (a2 ? S2.s_prev : S2.s_cur)[k * 32 + c]; }
+    // cell operands of phase C
+    const int c_slot = tid >> 8, c_kk = (tid & 255) >> 3, c_j = 8 * g + (tid & 7);
+    float c_gi[3] = {0.f, 0.f, 0.f}, c_bh[3] = {0.f, 0.f, 0.f}, c_mask = 1.f;
+    if (tid < 512 && G.s[c_slot].present) {
+        const HsSlot& S = G.s[c_slot];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            c_bh[q] = S.bhh[q * 256 + c_j];
+            c_gi[q] = c_slot == 0 ? S.gi[c_kk * 768 + q * 256 + c_j] : S.bih[q * 256 + c_j];
+        }
+        if (S.xdrop && S.mask) c_mask = S.mask[c_kk * 256 + c_j];
+    } else if (tid >= 512 && tid < 512 + NT && S2.present) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { c_bh[q] = S2.bhh[q * 32 + g]; c_gi[q] = S2.gi[(tid - 512) * 96 + q * 32 + g]; }
+    }
+
+    // ---- A. attention of the previous clip (SpatialAttention, EventAD.py:100-138): s_k = tanh(Hn_k).w, alpha = softmax
+    //         over the valid tracks, state_k = valid ? Hn_k * alpha_k : state kept
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (a0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p0 += hs_tanh(hn0[i]) * S0.w_att[c + 32 * i];
+    }
+    if (a1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p1 += hs_tanh(hn1[i]) * S1.w_att[c + 32 * i];
+    }
+    if (a2) p2 = hs_tanh(hnc) * S2.w_att[c];
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) { p0 += __shfl_xor(p0, d, 64); p1 += __shfl_xor(p1, d, 64); p2 += __shfl_xor(p2, d, 64); }
+    if (c == 0) { s_part[k] = p0; s_part[NT + k] = p1; s_part[2 * NT + k] = p2; }
+    if (tid < 3 * NT) {
+        const HsSlot& S = G.s[tid >> 5];
+        s_v[tid] = (S.present && S.hn_prev) ? S.valid_prev[tid & 31] : 0;
+    }
+    __syncthreads();
+    if (wave < 3) {                                          // one wave per slot; both half-waves compute the same 32 values
+        const int q = wave * NT + (lane & 31);
+        const bool vq = s_v[q] != 0;
+        float m = vq ? s_part[q] : -3.4e38f;
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        const float e = vq ? expf(s_part[q] - m) : 0.f;
+        float sum = e;
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        if (lane < 32) s_al[q] = vq ? e / sum : 0.f;
+    }
+    __syncthreads();
+    if (S0.present) {
+        const bool v = a0 && s_v[k] != 0; const float al = s_al[k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = c + 32 * i;
+            const float val = v ? hn0[i] * al : kp0[i];
+            sA[0][k][j] = val;
+            if (a0 && (j >> 3) == g) S0.s_cur[k * 256 + j] = val;
+        }
+        if (a0 && g == 0 && c == 0) S0.alpha_prev[k] = al;
+    }
+    if (S1.present) {
+        const bool v = a1 && s_v[NT + k] != 0; const float al = s_al[NT + k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = c + 32 * i;
+            const float val = v ? hn1[i] * al : kp1[i];
+            sA[1][k][j] = val;
+            if (a1 && (j >> 3) == g) S1.s_cur[k * 256 + j] = val;
+            sA[2][k][j] = xin[i];
+        }
+        if (a1 && g == 0 && c == 0) S1.alpha_prev[k] = al;
+    }
+    if (S2.present) {
+        const bool v = a2 && s_v[2 * NT + k] != 0; const float al = s_al[2 * NT + k];
+        const float val = v ? hnc * al : kpc;
+        sC[k][c] = val;
+        if (a2 && c == g) S2.s_cur[k * 32 + c] = val;
+        if (a2 && g == 0 && c == 0) S2.alpha_prev[k] = al;
+    }
+    __syncthreads();
+
+    // ---- B. products with this workgroup's gate rows.  MFMA 32x32x2: lane l supplies A[l & 31][k'] and B[k'][l & 31] for
+    //         k' = l >> 5; a lane loads 4 consecutive k as one float4 (k = 8t + 4h + i for half-wave h), so step (t, i) pairs
+    //         k = 8t + i with k = 8t + 4 + i -- any pairing that A and B share is a valid order of the sum over k.
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (mf_live && wave < 12) {
+        const float (*At)[HS_LD] = wave < 4 ? sA[0] : (wave < 8 ? sA[1] : sA[2]);
+        const int kc = (wave & 3) * 64;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float4 a = *(const float4*)&At[nn][kc + 8 * t + 4 * h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[t].w, acc, 0, 0, 0);
+        }
+    } else if (mf_live && wave == 12) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 a = *(const float4*)&sC[nn][8 * t + 4 * h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[t].w, acc, 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (wave < 13 && nn < 24) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][nn] = acc[r];
+    }
+    __syncthreads();
+
+    // ---- C. GRU cell (PyTorch gate order r, z, n) on this workgroup's columns
+    if (tid < 512) {
+        const int slot = c_slot, kk = c_kk, jj = tid & 7, j = c_j;
+        const HsSlot& S = G.s[slot];
+        if (S.present) {
+            float gh[3], gi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int w0 = 4 * slot, col = q * 8 + jj;
+                gh[q] = (((Red[w0][kk][col] + Red[w0 + 1][kk][col]) + Red[w0 + 2][kk][col]) + Red[w0 + 3][kk][col]) + c_bh[q];
+                if (slot == 0) gi[q] = c_gi[q];
+                else gi[q] = (((Red[8][kk][col] + Red[9][kk][col]) + Red[10][kk][col]) + Red[11][kk][col]) + c_gi[q];
+            }
+            const float r = hs_sigmoid(gi[0] + gh[0]), z = hs_sigmoid(gi[1] + gh[1]), n = hs_tanh(gi[2] + r * gh[2]);
+            const float hp = sA[slot][kk][j];
+            const float hn = (1.f - z) * n + z * hp;
+            float* gt = S.gates + kk * 768; float* go = S.gh_out + kk * 768;
+            gt[j] = r; gt[256 + j] = z; gt[512 + j] = n;
+            go[j] = gh[0]; go[256 + j] = gh[1]; go[512 + j] = gh[2];
+            S.hn[kk * 256 + j] = hn;
+            if (S.xdrop) S.xdrop[kk * 256 + j] = S.mask ? hn * c_mask : hn;
+        }
+    } else if (tid < 512 + NT && S2.present) {
+        const int kk = tid - 512;
+        float gh[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gh[q] = Red[12][kk][q] + c_bh[q];
+        const float r = hs_sigmoid(c_gi[0] + gh[0]), z = hs_sigmoid(c_gi[1] + gh[1]), n = hs_tanh(c_gi[2] + r * gh[2]);
+        const float hp = sC[kk][g];
+        const float hn = (1.f - z) * n + z * hp;
+        float* gt = S2.gates + kk * 96; float* go = S2.gh_out + kk * 96;
+        gt[g] = r; gt[32 + g] = z; gt[64 + g] = n;
+        go[g] = gh[0]; go[32 + g] = gh[1]; go[64 + g] = gh[2];
+        S2.hn[kk * 32 + g] = hn;
+    }
+}
+
+/* desc: HOST array, 3 slots x 18 int64: slot 0 = 256-wide GRU layer whose input product gi (incl. bias) is precomputed,
+ * slot 1 = 256-wide layer whose input product xin . wih^T + bih is computed here, slot 2 = 32-wide layer with precomputed gi.
+ * Per slot: [0] present (0 = skip the slot) [1] hn_prev f32[32,H] cell output of the previous clip (0 = there is none: the
+ * state is read from [6] as it is) [2] s_prev f32[32,H] state that entered the previous clip (kept for its invalid
+ * tracks) [3] valid_prev i32[32] [4] attention w f32[H] [5] alpha_prev out f32[32] [6] s_cur f32[32,H]: state entering
+ * this clip (out, unless [1] is 0) [7] whh f32[3H,H] [8] bhh [9] gi f32[32,3H] [10] xin f32[32,H] [11] wih f32[3H,H]
+ * [12] bih [13] gh out f32[32,3H] (state . whh^T + bhh) [14] gates out f32[32,3H] (r|z|n) [15] hn out f32[32,H]
+ * [16] dropout mask (0 = none) [17] xdrop out = hn * mask (0 = none). */
+extern "C" int eventad_head_stage_fwd(const int64_t* d, void* stream) {
+    if (!d) return EVAD_ERR_ARG;
+    HsGroup G;
+    bool any = false;
+    for (int i = 0; i < 3; ++i) {
+        const int64_t* q = d + 18 * i; HsSlot& S = G.s[i];
+        S.present = q[0] != 0;
+        S.hn_prev = (const float*)q[1]; S.s_prev = (const float*)q[2]; S.valid_prev = (const int*)q[3]; S.w_att = (const float*)q[4];
+        S.alpha_prev = (float*)q[5]; S.s_cur = (float*)q[6]; S.whh = (const float*)q[7]; S.bhh = (const float*)q[8];
+        S.gi = (const float*)q[9]; S.xin = (const float*)q[10]; S.wih = (const float*)q[11]; S.bih = (const float*)q[12];
+        S.gh_out = (float*)q[13]; S.gates = (float*)q[14]; S.hn = (float*)q[15]; S.mask = (const float*)q[16]; S.xdrop = (float*)q[17];
+        if (!S.present) continue;
+        any = true;
+        if (!S.s_cur || !S.whh || !S.bhh || !S.gh_out || !S.gates || !S.hn) return EVAD_ERR_ARG;
+        if (S.hn_prev && (!S.s_prev || !S.valid_prev || !S.w_att || !S.alpha_prev)) return EVAD_ERR_ARG;
+        if (i == 1 ? (!S.xin || !S.wih || !S.bih) : !S.gi) return EVAD_ERR_ARG;
+        if (((uintptr_t)S.whh & 15) || (i == 1 && ((uintptr_t)S.wih & 15))) return EVAD_ERR_ARG;
+    }
+    if (!any) return EVAD_OK;
+    static bool attr_set = false;
+    const int lds = (int)(HS_SMEM_FLOATS * sizeof(float));
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_head_stage_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return -2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_head_stage_fwd, dim3(HS_WGS), dim3(1024), lds, (hipStream_t)stream, G);
+    return evad_last_error();
+}

@@ -25,6 +25,9 @@ _TILE_CNT = os.environ.get("EVENTAD_TILE_CNT", "0") == "1"
 # Measured on C2 (same box, A/B): head graph 0.695 ms with, 0.630 ms without -- the extra loads sit on the one-workgroup
 # critical path and cost more than the 5 us launch they save.  Off.
 _KEEP_SLABS = os.environ.get("EVENTAD_KEEP_SLABS", "0") == "1"
+# forward recurrence: one fused launch per clip stage (attention of the previous clip + recurrent products + cell,
+# csrc/headstage.hip) instead of a grouped GEMM and a cell+attention launch.  0 = the two-launch form (kept for A/B runs).
+_STAGE_FWD = os.environ.get("EVENTAD_HEAD_STAGE", "1") == "1"
 
 
 class NativeHead:
@@ -94,8 +97,9 @@ class NativeHead:
         # the weight gradients (K = R rows, M x N = 768 x 256) and the chain's [32,768]x[768,256] (3 slabs of 32 x 256)
         w["part"] = [f(max(3 * 32 * 768, ((R + 255) // 256) * 768 * 256)) for _ in range(8)]
         w["cnt"] = [i(24 * 24) for _ in range(8)]                               # tile counters of those products (<= 768 x 768 outputs)
-        w["dwatt"] = f(2, 256)                                                  # per-layer accumulators of d soft_attention.weight
-        w["dwatt0"], w["dwatt1"] = w["dwatt"][0], w["dwatt"][1]
+        # accumulators of d soft_attention.weight (one per GRU layer) and d soft_attention_cor.weight: [l0 | cor | l1 | 0]
+        w["dwatt"] = f(2 * 288)
+        w["dwatt0"], w["dwattc"], w["dwatt1"] = w["dwatt"][:256], w["dwatt"][256:288], w["dwatt"][288:544]
         w["zero256"], w["zero32"] = f(NT, 256), f(NT, 32)
         w["D"] = f(2 * R, 256)                                                  # dropout masks (GRU inter-layer | fusion)
         self._B = B
@@ -149,8 +153,14 @@ class NativeHead:
         M = int(bbox.shape[0]) if bbox is not None else 0
         bbox_c = bbox.contiguous().float() if M else None
         bb_c = bbox_batch.contiguous().long() if M else None
-        lab_c = labels.contiguous().float() if (M and labels is not None) else None
-        call("eventad_head_tables", _rp(bbox_c), _rp(bb_c), M, _rp(lab_c), ptr(feats), B, int(width), int(height),
+        lab_c, label_col = None, -1
+        if M and labels is not None:
+            if (labels.dtype == torch.float32 and labels.dim() == 1 and labels.shape[0] == M and labels.stride(0) == 6
+                    and labels.data_ptr() - bbox_c.data_ptr() in range(0, 24, 4)):
+                label_col = (labels.data_ptr() - bbox_c.data_ptr()) // 4      # a column of bbox itself: read in place
+            else:
+                lab_c = labels.contiguous().float()
+        call("eventad_head_tables", _rp(bbox_c), _rp(bb_c), M, _rp(lab_c), label_col, ptr(feats), B, int(width), int(height),
              ptr(w["X"]), ptr(w["CO"]), ptr(w["target"]), ptr(w["valid"]), st)
         self.D1 = self.D2 = None
         if train:                                              # nn.GRU(dropout=.3) between layers; fusion Dropout(.3):
@@ -166,7 +176,10 @@ class NativeHead:
         # coordinate GRU on clip b and GRU layer 1 on clip b-1 (its input, the dropout'd layer-0 output of clip
         # b-1, and its state, the layer-1 attention of clip b-2, are both a stage old), so one stage is two
         # dependent launches -- a grouped GEMM and a fused cell+attention -- instead of five.
-        for b in range(B + 1):
+        if _STAGE_FWD:
+            self._gg(*input_proj)
+            self._forward_chain_fused(B, train)
+        for b in range(0 if _STAGE_FWD else B + 1):
             gemms, steps = (list(input_proj) if b == 0 else []), []
             if b < B:
                 r0, r1 = b * NT, (b + 1) * NT
@@ -196,6 +209,39 @@ class NativeHead:
             return (w["loss"][0], w["logits"].view(B, NT, 2), w["valid"].view(B, NT), w["target"].view(B, NT))
         return (w["loss"][0], w["logits"].view(B, NT, 2), w["valid"].view(B, NT).bool(), w["target"].view(B, NT).long())
 
+    def _forward_chain_fused(self, B, train):
+        """The clip-to-clip recurrence with one launch per stage (eventad_head_stage_fwd): stage b runs GRU layer 0 and the
+        coordinate GRU on clip b and GRU layer 1 on clip b-1; the attention that turns a clip's cell outputs into the next
+        clip's state is computed at the start of the stage that consumes it.  Fills the same buffers as the two-launch form
+        (the state after the LAST clip and its attention weights, which nothing reads, are not computed)."""
+        w, P = self.w, self.P
+        ev, co = "gru_net_event.gru.", "gru_net_cor.gru."
+        watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
+        st = torch.cuda.current_stream().cuda_stream
+        rows = lambda t, b: t[b * NT:(b + 1) * NT].data_ptr()
+        for b in range(B + 1):
+            d = (ctypes.c_int64 * 54)()
+            if b < B:
+                prev = b > 0
+                d[0:18] = [1, rows(w["H0n"], b - 1) if prev else 0, rows(w["S0"], b - 1) if prev else 0,
+                           rows(w["valid"], b - 1) if prev else 0, watt.data_ptr(), rows(w["AL0"], b - 1) if prev else 0,
+                           rows(w["S0"], b), P[ev + "weight_hh_l0"].data_ptr(), P[ev + "bias_hh_l0"].data_ptr(),
+                           rows(w["GI0"], b), 0, 0, 0, rows(w["GH0"], b), rows(w["G0"], b), rows(w["H0n"], b),
+                           rows(self.D1, b) if train else 0, rows(w["X1"], b)]
+                d[36:54] = [1, rows(w["HCn"], b - 1) if prev else 0, rows(w["SC"], b - 1) if prev else 0,
+                            rows(w["valid"], b - 1) if prev else 0, wattc.data_ptr(), rows(w["ALC"], b - 1) if prev else 0,
+                            rows(w["SC"], b), P[co + "weight_hh_l0"].data_ptr(), P[co + "bias_hh_l0"].data_ptr(),
+                            rows(w["GIC"], b), 0, 0, 0, rows(w["GHC"], b), rows(w["GC"], b), rows(w["HCn"], b), 0, 0]
+            if b >= 1:
+                q = b - 1
+                prev = q > 0
+                d[18:36] = [1, rows(w["H1n"], q - 1) if prev else 0, rows(w["S1"], q - 1) if prev else 0,
+                            rows(w["valid"], q - 1) if prev else 0, watt.data_ptr(), rows(w["AL1"], q - 1) if prev else 0,
+                            rows(w["S1"], q), P[ev + "weight_hh_l1"].data_ptr(), P[ev + "bias_hh_l1"].data_ptr(),
+                            0, rows(w["X1"], q), P[ev + "weight_ih_l1"].data_ptr(), P[ev + "bias_ih_l1"].data_ptr(),
+                            rows(w["GH1"], q), rows(w["G1"], q), rows(w["H1n"], q), 0, 0]
+            call("eventad_head_stage_fwd", ctypes.cast(d, ctypes.c_void_p), st)
+
     # ----------------------------------------------------------------- backward
     def backward(self):
         """Fills `self.grads` (d loss / d every used parameter) for the last forward."""
@@ -204,7 +250,9 @@ class NativeHead:
         st = torch.cuda.current_stream().cuda_stream
         R = B * NT
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
-        self.grads.zero_()
+        # every used gradient entry is written (not accumulated) below; the attention vectors accumulate over the clips in
+        # small buffers of their own (cleared here), the alignment pads of the flat buffer are zero from allocation
+        w["dwatt"].zero_()
         call("eventad_out_bwd", ptr(w["dlog"]), _rp(P[fu + "fusion.3.weight"]), ptr(w["F1r"]), _rp(self.D2), R, ptr(w["dPre"]),
              _rp(G[fu + "fusion.3.weight"]), _rp(G[fu + "fusion.3.bias"]), st)
         dE, dC = w["dZCAT"], w["dZCAT"][:, 256:]
@@ -222,8 +270,7 @@ class NativeHead:
         n0, n1, nc = w["dS0a"], w["dS1a"], w["dSCa"]
         o0, o1, oc = w["dS0b"], w["dS1b"], w["dSCb"]
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
-        gattc = G["soft_attention_cor.weight"]
-        w["dwatt"].zero_()
+        gattc = w["dwattc"]
         # reverse wavefront: stage b runs layer 1 + the coordinate GRU on clip b and layer 0 on clip b+1 (whose
         # dX1 and dS0 come out of the previous stage's GEMMs): fused attention+cell backward, then one grouped GEMM
         # The [32,768]x[768,256] products of the chain have 3 split-K slabs; with _KEEP_SLABS the NEXT stage's fused kernel
@@ -269,7 +316,11 @@ class NativeHead:
                 dc, nc, oc = nc, oc, nc
             if b + 1 < B:
                 d0, n0, o0 = n0, o0, n0
-        torch.add(w["dwatt0"], w["dwatt1"], out=G["soft_attention.weight"].view(-1))
+        # soft_attention.weight (256) and soft_attention_cor.weight (32) are neighbours in the flat gradient buffer:
+        # [dwatt0 | dwattc] + [dwatt1 | 0] lands on both with one launch
+        o = self.off["soft_attention.weight"]
+        assert self.off["soft_attention_cor.weight"] == o + 256
+        torch.add(w["dwatt"][:288], w["dwatt"][288:], out=self.grads[o:o + 288])
         # weight gradients of the recurrent layers, batched over all clips: ONE launch (+ one reduce)
         self._gg((1, 0, w["dGI0"], 768, w["X"], 64, G[ev + "weight_ih_l0"], 64, 768, 64, R),
                  (1, 0, w["dGH0"], 768, w["S0"], 256, G[ev + "weight_hh_l0"], 256, 768, 256, R),

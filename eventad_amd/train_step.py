@@ -52,6 +52,13 @@ class TrainStep:
         # capture from the two graphs' stand-alone times (a head that is short against its backbone gets no CUs of its
         # own: they would only be taken from the backbone); 0: never; n > 0: always n CUs.
         self.head_cus = int(os.environ.get("EVENTAD_HEAD_CUS", "-1"))
+        # two-graph pipeline: number of backbone chains (each with its own workspace set, input buffers, feature buffer and
+        # stream; batch k runs on chain k % n).  The backbone graph is ~45 launches, half of them latency bound: with three
+        # chains the backbone passes of consecutive batches overlap and fill each other's gaps (C2: 0.84 -> 0.62 ms per
+        # batch for two passes in flight), while the head updates stay strictly ordered.  0 (default): 3 chains when the
+        # CNN features come precomputed with the batch and the head gets CUs of its own, else 2 (= plain double buffering:
+        # with the live CNN trunk the backbone's kernels fill the chip and overlapping them gains nothing).
+        self.backbone_chains = int(os.environ.get("EVENTAD_BACKBONE_CHAINS", "0"))
 
     # ------------------------------------------------------------------ pieces
     def _head_update(self, feats, head_in, labels=None):
@@ -118,11 +125,20 @@ class TrainStep:
 
     # ---- software pipeline across steps, eager:   stream G: backbone + ROI pooling of batch k+1   (-> feats_next)
     #                                                stream H: head update of batch k                 (on feats_cur)
-    def _streams(self, masked=False):
-        """The two streams of the pipelined modes, both at the default priority (work on streams of different priorities
-        has hung on this platform).  masked=True: the pair with disjoint CU sets -- `head_cus` CUs for the head's stream,
-        the rest for the backbone's -- so the head's small dependent launches do not queue behind the backbone's
-        chip-wide grids."""
+    def _streams(self, masked=False, chains=1):
+        """The streams of the pipelined modes, all at the default priority (work on streams of different priorities has
+        hung on this platform): (backbone stream, head stream), or ([backbone streams], head stream) for chains > 1.
+        masked=True: disjoint CU sets -- `head_cus` CUs for the head's stream, the rest for the backbone's streams -- so
+        the head's small dependent launches do not queue behind the backbone's chip-wide grids."""
+        if chains > 1:
+            key = "_chain_streams_m" if masked else "_chain_streams"
+            have = getattr(self, key, None)
+            if have is None or len(have[0]) < chains:
+                sg0, sh = self._streams(masked)
+                extra = [self._new_backbone_stream(masked) for _ in range(chains - 1)]
+                setattr(self, key, ([sg0] + extra, sh))
+            lst, sh = getattr(self, key)
+            return lst[:chains], sh
         if not masked:
             if getattr(self, "_sg", None) is None:
                 self._sg, self._sh = torch.cuda.Stream(), torch.cuda.Stream()
@@ -139,6 +155,7 @@ class TrainStep:
             for cu in range(total):
                 (hm if cu < n_head else bm)[cu // 32] |= 1 << (cu % 32)
             self._raw_streams, out = [], []
+            self._backbone_mask = (bm, words)
             for m in (bm, hm):
                 h = ctypes.c_void_p()
                 call("eventad_stream_create_cu_mask", ctypes.cast(m, ctypes.c_void_p), words, ctypes.byref(h))
@@ -149,6 +166,18 @@ class TrainStep:
             atexit.register(self.close)                        # HIP streams made outside torch: destroyed before the runtime unloads
         return self._sgm, self._shm
 
+    def _new_backbone_stream(self, masked):
+        """One more stream for a further backbone chain (same CU set as the first backbone stream)."""
+        if not masked:
+            return torch.cuda.Stream()
+        import ctypes
+        from ._lib import call
+        bm, words = self._backbone_mask
+        h = ctypes.c_void_p()
+        call("eventad_stream_create_cu_mask", ctypes.cast(bm, ctypes.c_void_p), words, ctypes.byref(h))
+        self._raw_streams.append(h)
+        return torch.cuda.ExternalStream(h.value)
+
     def close(self):
         """Destroy the CU-masked streams (idempotent).  Graphs captured by this object must not be replayed afterwards."""
         raw, self._raw_streams = getattr(self, "_raw_streams", None) or [], []
@@ -156,6 +185,7 @@ class TrainStep:
             from ._lib import call
             torch.cuda.synchronize()
             self._sgm = self._shm = None
+            self._chain_streams_m = None
             for h in raw:
                 call("eventad_stream_destroy", h)
 
@@ -184,47 +214,60 @@ class TrainStep:
         self._feats_cur.copy_(feats_next)
         return loss, norm
 
-    # ---- the same pipeline as single-branch hipGraphs on two streams coupled only by events, double-buffered by step
-    # parity p = k % 2 so that nothing is copied between the stages and the backbone of batch k+1 starts the moment the
-    # backbone of batch k ends:
-    #     backbone graph p  writes its own feature tensor feats[p]            (stream G)
-    #     head graph p      reads feats[p] and the boxes / labels in_h[p]     (stream H)
-    # Per replay k (p = k % 2, p' = (k+1) % 2):
-    #     stream H: wait(backbone k done); head graph p; record(head k done)
-    #     stream G: wait(head k-1 done: it was the last reader of feats[p'] and in_h[p']); in_b, in_h[p'] <- batch k+1 (if
-    #               given); backbone graph p'; record(backbone k+1 done)
-    # The step object owns the static inputs: `in_b` (a whole batch: the backbone graphs' input) and `in_h[0..1]` (the
-    # boxes of the batch whose features the head graph of that parity consumes), so the head always sees the boxes and
-    # labels of the batch that produced its features.
+    # ---- the same pipeline as single-branch hipGraphs on streams coupled only by events, buffered per CHAIN c = k % n so
+    # that nothing is copied between the stages:
+    #     backbone graph c  reads its own input batch in_b[c], works in workspace set c, writes its own feature tensor
+    #                       feats[c]                                                           (stream G[c])
+    #     head graph c      reads feats[c] and the boxes / labels in_h[c]                      (stream H)
+    # Per replay k (c = k % n, c' = (k+1) % n):
+    #     stream H:     wait(backbone k done); head graph c; record(head k done)
+    #     stream G[c']: wait(head k+1-n done: it was the last reader of feats[c'] and in_h[c']); in_b[c'], in_h[c'] <- batch
+    #                   k+1 (if given); backbone graph c'; record(backbone k+1 done)
+    # The head updates run strictly in order on one stream.  With n = 2 this is double buffering: the backbone of batch k+1
+    # overlaps the head update of batch k.  With n = 3 -- and a caller that issues steps without a per-step join -- the
+    # backbone passes of batches k+1 and k+2 are in flight together (different streams, different workspace sets) and fill
+    # each other's launch gaps.  The step object owns the static inputs, so the head always sees the boxes and labels of
+    # the batch that produced its features.
     def capture_dual(self, data, warmup=3):
         """data: the first batch (formatted, on the device).  Captures the graphs on copies of it and starts the backbone
         pass of that batch.  Every later batch must have the same shapes (events N, boxes M, clips B)."""
         d = self._dual = {}
-        in_b = d["in_b"] = data.clone()
-        in_h = d["in_h"] = [_HeadInputs(in_b), _HeadInputs(in_b)]
-        d["in_b_id"], d["in_h_id"] = 0, [0, 0]                 # which loaded batch each buffer holds
-        self.prime(in_b)
+        in_b = d["in_b"] = [data.clone()]
+        in_h = d["in_h"] = [_HeadInputs(in_b[0])]
+        self.prime(in_b[0])
         snap = self.snapshot()                                 # warm-up steps are undone: the first replay consumes `data`
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.pipelined_step(in_h[0], None, in_b)
+                self.pipelined_step(in_h[0], None, in_b[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._pin_workspaces()
         d["gb"], d["gh"], d["feats"], d["out"] = [], [], [], []
-        with torch.no_grad():
-            for p in range(2):
+        native = getattr(self.model.dagr_model.backbone, "_native", None)
+
+        def add_chain():
+            c = len(d["gb"])
+            if c > 0:
+                in_b.append(data.clone())
+                in_h.append(_HeadInputs(in_b[c]))
+            with torch.no_grad():
+                if native is not None:
+                    native.select_workspace(c)
+                    if c > 0:                                  # allocate workspace set c outside the capture
+                        self.model.extract_features(in_b[c], frames=(1,))
+                        torch.cuda.synchronize()
                 gb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                    feats = self.model.extract_features(in_b, frames=(1,))
+                    feats = self.model.extract_features(in_b[c], frames=(1,))
                 with torch.cuda.graph(gh, capture_error_mode="thread_local"):
-                    out = self._head_update(feats, in_h[p])
-                d["gb"].append(gb); d["gh"].append(gh); d["feats"].append(feats); d["out"].append(out)
-        d["ev_b"] = [torch.cuda.Event(), torch.cuda.Event()]
-        d["ev_h"] = [torch.cuda.Event(), torch.cuda.Event()]
-        d["k"], d["drained"] = 0, False
+                    out = self._head_update(feats, in_h[c])
+                if native is not None:
+                    native.select_workspace(0)
+            d["gb"].append(gb); d["gh"].append(gh); d["feats"].append(feats); d["out"].append(out)
+
+        add_chain(); add_chain()
         d["masked"] = self.head_cus > 0
         if self.head_cus < 0:                                  # stand-alone times of the two graphs decide
             t = []
@@ -239,14 +282,27 @@ class TrainStep:
                 t.append(a.elapsed_time(b) / 3)
             d["graph_ms"] = tuple(t)
             d["masked"] = t[1] > 0.5 * t[0]
+        n = self.backbone_chains
+        if n <= 0:
+            n = 3 if (d["masked"] and native is not None and getattr(data, "image_feats", None) is not None) else 2
+        n = max(2, n)
+        while len(d["gb"]) < n:
+            add_chain()
+        d["n"] = n
+        d["in_b_id"], d["in_h_id"] = [0] * n, [0] * n          # which loaded batch each buffer holds
+        d["ev_b"] = [torch.cuda.Event() for _ in range(n)]
+        d["ev_h"] = [torch.cuda.Event() for _ in range(n)]
+        d["k"], d["drained"] = 0, False
         self.restore(snap)                                     # warm-up and timing replays were real steps: undone here
         torch.cuda.synchronize()
         main = torch.cuda.current_stream()
-        sg, sh = self._streams(d["masked"])
-        sg.wait_stream(main); sh.wait_stream(main)
-        with torch.cuda.stream(sg):                            # the first batch enters the pipeline
+        sgs, sh = self._streams(d["masked"], n)
+        for sg in sgs:
+            sg.wait_stream(main)
+        sh.wait_stream(main)
+        with torch.cuda.stream(sgs[0]):                        # the first batch enters the pipeline
             d["gb"][0].replay()
-            d["ev_b"][0].record(sg)
+            d["ev_b"][0].record(sgs[0])
         self._g_loss, self._g_norm = d["out"][0]
         return d["gb"], d["gh"]
 
@@ -265,67 +321,75 @@ class TrainStep:
             for dst, src in zip(in_b.image_feats, batch.image_feats):
                 dst.copy_(src, non_blocking=True)
 
-    def _issue_backbone(self, d, p_next, next_batch, sg):
-        """Stream G part of a step: load the next batch (if any), backbone graph of parity p_next."""
+    def _issue_backbone(self, d, c, next_batch, sg):
+        """Backbone-stream part of a step: load the next batch into chain c's buffers (if given; None = chain c runs the
+        batch it holds again), backbone graph of chain c."""
         with torch.cuda.stream(sg):
-            sg.wait_event(d["ev_h"][p_next])                   # the last reader of feats[p_next] / in_h[p_next] is done
+            sg.wait_event(d["ev_h"][c])                        # the last reader of feats[c] / in_h[c] is done
             if next_batch is not None:
-                self.load_into(d["in_b"], next_batch)
-                d["in_b_id"] += 1
-            if d["in_h_id"][p_next] != d["in_b_id"]:
-                d["in_h"][p_next].copy_from(d["in_b"])
-                d["in_h_id"][p_next] = d["in_b_id"]
-            d["gb"][p_next].replay()
-            d["ev_b"][p_next].record(sg)
+                self.load_into(d["in_b"][c], next_batch)
+                d["in_b_id"][c] += 1
+            if d["in_h_id"][c] != d["in_b_id"][c]:
+                d["in_h"][c].copy_from(d["in_b"][c])
+                d["in_h_id"][c] = d["in_b_id"][c]
+            d["gb"][c].replay()
+            d["ev_b"][c].record(sg)
 
     def replay_dual(self, next_batch=None, join=True):
         """One pipelined step: head update of the batch loaded by the previous call (or capture_dual) || backbone of
-        `next_batch` (formatted; on the device or in pinned host memory; None = run the resident batch again).
-        Returns (loss, grad_norm) of the batch the head consumed -- static device tensors of that step parity, valid after
-        a synchronisation and until the call after next.  join=False: no per-step barrier with the caller's stream; call
-        flush() -- or synchronise -- before reading results or re-using the memory of a `next_batch` passed earlier."""
+        `next_batch` (formatted; on the device or in pinned host memory; None = the chain whose turn it is runs the batch it
+        holds again).  Returns (loss, grad_norm) of the batch the head consumed -- static device tensors of that chain, valid
+        after a synchronisation and until the chain's next turn (n calls later).  join=False: no per-step barrier with the
+        caller's stream (what lets more than one backbone pass be in flight); call flush() -- or synchronise -- before
+        reading results or re-using the memory of a `next_batch` passed earlier."""
         d = self._dual
+        n = d["n"]
         main = torch.cuda.current_stream()
-        sg, sh = self._streams(d["masked"])
-        if join or next_batch is not None:
-            sg.wait_stream(main)                               # next_batch was produced on the caller's stream
-        if join:
-            sh.wait_stream(main)
+        sgs, sh = self._streams(d["masked"], n)
+        c, c_next = d["k"] % n, (d["k"] + 1) % n
         if d["drained"]:                                       # after flush(): restart the pipeline with this batch
             d["drained"] = False
-            self._issue_backbone(d, d["k"] % 2, next_batch, sg)
+            if join or next_batch is not None:
+                sgs[c].wait_stream(main)
+            self._issue_backbone(d, c, next_batch, sgs[c])
             if join:
-                main.wait_stream(sg)
+                main.wait_stream(sgs[c])
             return None
-        p = d["k"] % 2
+        if join or next_batch is not None:
+            sgs[c_next].wait_stream(main)                      # next_batch was produced on the caller's stream
+        if join:
+            sh.wait_stream(main)
         with torch.cuda.stream(sh):
-            sh.wait_event(d["ev_b"][p])
-            d["gh"][p].replay()
-            d["ev_h"][p].record(sh)
-        self._issue_backbone(d, 1 - p, next_batch, sg)
+            sh.wait_event(d["ev_b"][c])
+            d["gh"][c].replay()
+            d["ev_h"][c].record(sh)
+        self._issue_backbone(d, c_next, next_batch, sgs[c_next])
         d["k"] += 1
         if join:
-            main.wait_stream(sg); main.wait_stream(sh)
-        self._g_loss, self._g_norm = d["out"][p]
-        return d["out"][p]
+            main.wait_stream(sgs[c_next]); main.wait_stream(sh)
+        self._g_loss, self._g_norm = d["out"][c]
+        return d["out"][c]
 
     def flush(self):
         """Drain the pipeline: head update of the last loaded batch, no new backbone pass.  -> (loss, grad_norm).
         The next replay_dual(batch) restarts the pipeline with `batch` (and returns None: no head update in that call)."""
         d = self._dual
+        n = d["n"]
         main = torch.cuda.current_stream()
-        sg, sh = self._streams(d["masked"])
+        sgs, sh = self._streams(d["masked"], n)
         sh.wait_stream(main)
-        p = d["k"] % 2
+        c = d["k"] % n
         with torch.cuda.stream(sh):
-            sh.wait_event(d["ev_b"][p])
-            d["gh"][p].replay()
-            d["ev_h"][p].record(sh)
+            sh.wait_event(d["ev_b"][c])
+            d["gh"][c].replay()
+            d["ev_h"][c].record(sh)
         d["k"] += 1
         d["drained"] = True
-        main.wait_stream(sh); main.wait_stream(sg)
-        self._g_loss, self._g_norm = d["out"][p]
-        return d["out"][p]
+        main.wait_stream(sh)
+        for sg in sgs:
+            main.wait_stream(sg)
+        self._g_loss, self._g_norm = d["out"][c]
+        return d["out"][c]
 
     def check(self):
         """Lazy, synchronising: raises if a step saw a non-finite gradient norm (the reference raises at

@@ -213,9 +213,11 @@ int eventad_roi_pool(const float* node_x, const float* node_pos, const int32_t* 
 int eventad_gemm_f32_ex(int trans_a, int trans_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                         int M, int N, int K, const float* bias, int relu, int accumulate, void* stream);
 /* (clip, track) tables + current-frame feature gather: replaces EventAD.py:229-255.  X f32[B*32,64],
- * CO f32[B*32,4], target/valid i32[B*32]; labels = bbox[:,4] (nullable). */
-int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, const float* labels, const float* feats,
-                        int B, int width, int height, float* X, float* CO, int32_t* target, int32_t* valid, void* stream);
+ * CO f32[B*32,4], target/valid i32[B*32]; labels f32[M] (nullable); with labels NULL and label_col in 0..5 the label of
+ * a box is that column of its bbox row (the reference's callers pass labels = bbox[:,4]); label_col < 0: targets 0. */
+int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, const float* labels, int label_col,
+                        const float* feats, int B, int width, int height, float* X, float* CO, int32_t* target,
+                        int32_t* valid, void* stream);
 /* Fused recurrent step of the head (Event_GRUNet / Cor_GRUNet cell, gate order r,z,n, + SpatialAttention over the valid
  * tracks; models/EventAD.py:62-138, 320-323) and its backward: GRU cell + attention
  * of one clip, one 1024-thread workgroup per problem, up to 3 problems per launch.
@@ -228,6 +230,19 @@ int eventad_head_tables(const float* bbox, const int64_t* bbox_batch, int M, con
  * [18] dx_extra slabs f32[n][32][H] (0=none): dx_extra := sum of slabs (the [7] pointer is then ignored) [19] n. */
 int eventad_gru_att_fwd_group(int n_prob, const int64_t* desc, void* stream);
 int eventad_gru_att_bwd_group(int n_prob, const int64_t* desc, void* stream);
+/* One clip stage of the head's forward recurrence in ONE launch (32 workgroups x 1024 threads, 142 KB of LDS each): the
+ * SpatialAttention of the previous clip (models/EventAD.py:100-138, 320-323; recomputed by every workgroup), the
+ * recurrent products state . Whh^T of up to three GRU layers -- and, for slot 1, the input product -- for the
+ * workgroup's hidden columns (fp32 MFMA), and the GRU cell (EventAD.py:62-97; gate order r,z,n).  Replaces the pair
+ * eventad_gemm_group + eventad_gru_att_fwd_group per clip; the buffers it fills are the ones eventad_gru_att_bwd_group reads.
+ * desc = HOST array, 3 slots x 18 int64: slot 0 = 256-wide layer, input product gi (incl. bias) precomputed; slot 1 =
+ * 256-wide layer, input product xin . wih^T + bih computed here; slot 2 = 32-wide layer, gi precomputed.  Per slot:
+ * [0] present [1] hn_prev f32[32,H] cell output of the previous clip (0 = none: the state is read from [6] as it is)
+ * [2] s_prev f32[32,H] state that entered the previous clip (kept for invalid tracks) [3] valid_prev i32[32]
+ * [4] attention w f32[H] [5] alpha_prev out f32[32] [6] s_cur f32[32,H] state entering this clip (out unless [1] = 0)
+ * [7] whh f32[3H,H] [8] bhh [9] gi f32[32,3H] [10] xin f32[32,H] [11] wih f32[3H,H] [12] bih [13] gh out f32[32,3H]
+ * [14] gates out f32[32,3H] [15] hn out f32[32,H] [16] dropout mask (0 = none) [17] xdrop out = hn * mask (0 = none). */
+int eventad_head_stage_fwd(const int64_t* desc, void* stream);
 /* Up to 8 independent small GEMMs per launch (one workgroup per 32x32 tile, its 4 waves split K in 64-deep
  * chunks and are summed in wave order = deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B
  * [2] part scratch f32[ceil(K/256)][M][N] (only when K > 256) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K

@@ -140,7 +140,8 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
     from eventad_amd.train_step import TrainStep
     W = H = 64; B = 3; n = 3000
     results = []
-    for mode in ("sequential", "pipelined", "graph", "dual", "dual_nojoin", "dual_masked", "dual_unmasked_nojoin"):
+    for mode in ("sequential", "pipelined", "graph", "dual", "dual_nojoin", "dual_masked", "dual_unmasked_nojoin",
+                 "dual_masked_nojoin_3chains", "dual_unmasked_nojoin_4chains", "dual_2chains"):
         args, model, sd, head_sd, raw, data = _build(W, H, B, n)
         from dagr.utils.buffers import format_data
         batches = [data] + [format_data(synthetic.make_batch(W, H, n, B, first_clip=3 * k, with_image=False,
@@ -165,9 +166,12 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
         else:
             join = not mode.endswith("nojoin")
             if "masked" in mode:                             # force / forbid the CU partition (default: decided by timing)
-                ts.head_cus = 32 if mode == "dual_masked" else 0
+                ts.head_cus = 0 if "unmasked" in mode else 32
+            if "chains" in mode:                             # backbone chains (default: 3 with the CU partition, else 2)
+                ts.backbone_chains = int(mode[-7])
             ts.capture_dual(batches[0], warmup=2)
-            assert ts._dual["masked"] == (mode == "dual_masked") or "masked" not in mode
+            assert ts._dual["masked"] == ("unmasked" not in mode) or "masked" not in mode
+            assert ts._dual["n"] == (int(mode[-7]) if "chains" in mode else (3 if ts._dual["masked"] else 2))
             for b in batches[1:]:
                 loss, norm = ts.replay_dual(b, join=join)
                 if join:

@@ -1,0 +1,43 @@
+"""Experiment: throughput of TWO backbone+ROI graphs (independent workspaces) replayed concurrently on two streams,
+against one graph replayed back to back.  The backbone is a chain of ~45 launches, half of them latency bound: two
+interleaved chains fill each other's gaps."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from eventad_amd import synthetic
+from eventad_amd.dagr.utils.buffers import format_data
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+W, H, n, B, live = synthetic.CONFIGS[cfg]
+dev = torch.device("cuda:0")
+graphs, keep = [], []
+for i in range(2):
+    args, model, sd = bench.build_model(W, H, B, dev, live_cnn=live)
+    model.train()
+    data = format_data(synthetic.make_config_batch(cfg, first_clip=8 * i).to(dev))
+    with torch.no_grad():
+        for _ in range(3):
+            model.extract_features(data, frames=(1,))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            f = model.extract_features(data, frames=(1,))
+    graphs.append(g); keep.append((model, data, f))
+s = [torch.cuda.Stream(), torch.cuda.Stream()]
+E = lambda: torch.cuda.Event(enable_timing=True)
+def run(which, reps=40):
+    torch.cuda.synchronize()
+    a, b = E(), E()
+    a.record()
+    for st in s:
+        st.wait_event(a)
+    for _ in range(reps):
+        for i in which:
+            with torch.cuda.stream(s[i]):
+                graphs[i].replay()
+    for st in s:
+        torch.cuda.current_stream().wait_stream(st)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / (reps * len(which))
+for _ in range(2):
+    print("one chain: %.3f ms per batch; two interleaved chains: %.3f ms per batch" % (run([0]), run([0, 1])))
