@@ -30,7 +30,7 @@ __device__ __forceinline__ float hs_tanh(float x) { return 1.f - 2.f / (__expf(2
 struct HsSlot {
     const float* hn_prev; const float* s_prev; const int* valid_prev; const float* w_att; float* alpha_prev; float* s_cur;
     const float* whh; const float* bhh; const float* gi; const float* xin; const float* wih; const float* bih;
-    float* gh_out; float* gates; float* hn; const float* mask; float* xdrop; int present;
+    float* gh_out; float* gates; float* hn; const float* mask; float* xdrop; float* ghr_out; int present;
 };
 struct HsGroup { HsSlot s[3]; };     // [0] 256-wide, input product precomputed; [1] 256-wide, input product xin . Wih^T here; [2] 32-wide
 
@@ -202,11 +202,12 @@ __global__ __launch_bounds__(1024) void k_head_stage_fwd(HsGroup G) {
         const int slot = c_slot, kk = c_kk, jj = tid & 7, j = c_j;
         const HsSlot& S = G.s[slot];
         if (S.present) {
-            float gh[3], gi[3];
+            float gh[3], gi[3], raw[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int w0 = 4 * slot, col = q * 8 + jj;
-                gh[q] = (((Red[w0][kk][col] + Red[w0 + 1][kk][col]) + Red[w0 + 2][kk][col]) + Red[w0 + 3][kk][col]) + c_bh[q];
+                raw[q] = ((Red[w0][kk][col] + Red[w0 + 1][kk][col]) + Red[w0 + 2][kk][col]) + Red[w0 + 3][kk][col];
+                gh[q] = raw[q] + c_bh[q];
                 if (slot == 0) gi[q] = c_gi[q];
                 else gi[q] = (((Red[8][kk][col] + Red[9][kk][col]) + Red[10][kk][col]) + Red[11][kk][col]) + c_gi[q];
             }
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(1024) void k_head_stage_fwd(HsGroup G) {
             float* gt = S.gates + kk * 768; float* go = S.gh_out + kk * 768;
             gt[j] = r; gt[256 + j] = z; gt[512 + j] = n;
             go[j] = gh[0]; go[256 + j] = gh[1]; go[512 + j] = gh[2];
+            if (S.ghr_out) { float* gr = S.ghr_out + kk * 768; gr[j] = raw[0]; gr[256 + j] = raw[1]; gr[512 + j] = raw[2]; }
             S.hn[kk * 256 + j] = hn;
             if (S.xdrop) S.xdrop[kk * 256 + j] = S.mask ? hn * c_mask : hn;
         }
@@ -230,29 +232,31 @@ __global__ __launch_bounds__(1024) void k_head_stage_fwd(HsGroup G) {
         float* gt = S2.gates + kk * 96; float* go = S2.gh_out + kk * 96;
         gt[g] = r; gt[32 + g] = z; gt[64 + g] = n;
         go[g] = gh[0]; go[32 + g] = gh[1]; go[64 + g] = gh[2];
+        if (S2.ghr_out) { float* gr = S2.ghr_out + kk * 96; gr[g] = Red[12][kk][0]; gr[32 + g] = Red[12][kk][1]; gr[64 + g] = Red[12][kk][2]; }
         S2.hn[kk * 32 + g] = hn;
     }
 }
 
-/* desc: HOST array, 3 slots x 18 int64: slot 0 = 256-wide GRU layer whose input product gi (incl. bias) is precomputed,
+/* desc: HOST array, 3 slots x 19 int64: slot 0 = 256-wide GRU layer whose input product gi (incl. bias) is precomputed,
  * slot 1 = 256-wide layer whose input product xin . wih^T + bih is computed here, slot 2 = 32-wide layer with precomputed gi.
  * Per slot: [0] present (0 = skip the slot) [1] hn_prev f32[32,H] cell output of the previous clip (0 = there is none: the
  * state is read from [6] as it is) [2] s_prev f32[32,H] state that entered the previous clip (kept for its invalid
  * tracks) [3] valid_prev i32[32] [4] attention w f32[H] [5] alpha_prev out f32[32] [6] s_cur f32[32,H]: state entering
  * this clip (out, unless [1] is 0) [7] whh f32[3H,H] [8] bhh [9] gi f32[32,3H] [10] xin f32[32,H] [11] wih f32[3H,H]
  * [12] bih [13] gh out f32[32,3H] (state . whh^T + bhh) [14] gates out f32[32,3H] (r|z|n) [15] hn out f32[32,H]
- * [16] dropout mask (0 = none) [17] xdrop out = hn * mask (0 = none). */
+ * [16] dropout mask (0 = none) [17] xdrop out = hn * mask (0 = none) [18] ghr out f32[32,3H] = state . whh^T without the
+ * bias (0 = none; read by eventad_head_stage_bwd). */
 extern "C" int eventad_head_stage_fwd(const int64_t* d, void* stream) {
     if (!d) return EVAD_ERR_ARG;
     HsGroup G;
     bool any = false;
     for (int i = 0; i < 3; ++i) {
-        const int64_t* q = d + 18 * i; HsSlot& S = G.s[i];
+        const int64_t* q = d + 19 * i; HsSlot& S = G.s[i];
         S.present = q[0] != 0;
         S.hn_prev = (const float*)q[1]; S.s_prev = (const float*)q[2]; S.valid_prev = (const int*)q[3]; S.w_att = (const float*)q[4];
         S.alpha_prev = (float*)q[5]; S.s_cur = (float*)q[6]; S.whh = (const float*)q[7]; S.bhh = (const float*)q[8];
         S.gi = (const float*)q[9]; S.xin = (const float*)q[10]; S.wih = (const float*)q[11]; S.bih = (const float*)q[12];
-        S.gh_out = (float*)q[13]; S.gates = (float*)q[14]; S.hn = (float*)q[15]; S.mask = (const float*)q[16]; S.xdrop = (float*)q[17];
+        S.gh_out = (float*)q[13]; S.gates = (float*)q[14]; S.hn = (float*)q[15]; S.mask = (const float*)q[16]; S.xdrop = (float*)q[17]; S.ghr_out = (float*)q[18];
         if (!S.present) continue;
         any = true;
         if (!S.s_cur || !S.whh || !S.bhh || !S.gh_out || !S.gates || !S.hn) return EVAD_ERR_ARG;
@@ -271,5 +275,247 @@ extern "C" int eventad_head_stage_fwd(const int64_t* d, void* stream) {
         attr_set = true;
     }
     hipLaunchKernelGGL(k_head_stage_fwd, dim3(HS_WGS), dim3(1024), lds, (hipStream_t)stream, G);
+    return evad_last_error();
+}
+
+// =============================================================================================
+// Backward of one clip stage in ONE launch (replaces cell + attention backward, the grouped products dG . W that carry
+// the gradient to the previous clip's state, and the launch that summed their split-K slabs).
+//
+// Workgroup g again owns hidden columns 8g .. 8g+7 (column g of the coordinate GRU).  What makes the backward stage
+// awkward is the attention: d alpha needs, per track, the dot product over the WHOLE row  da_k = sum_j dS[k,j] Hn[k,j],
+// where dS = (element-wise part) + dG_next . Whh is itself a product that no workgroup holds completely.  Here the
+// PRODUCING stage (the one that computed dG_next) already writes, per workgroup, its share of that dot product:
+//     sum_j (dG_next . Whh)[k,j] Hn[k,j] = sum_n dG_next[k,n] (Whh Hn_k)[n],   (Whh Hn_k)[n] = ghr_next[k,n] / alpha_k
+// -- ghr_next is the forward's raw recurrent product of the next clip, whose state is alpha_k Hn_k for a valid track --
+// so a stage starts by adding 32 partial dots per track instead of waiting for a reduction over rows.  Then
+//   1. the products dG_next . W for this workgroup's 8 columns: A rows straight from memory (float4 along k), the 8-column
+//      slices of W staged in LDS, fp32 MFMA 16x16x4, K split over 4 waves per product, partial sums added in wave order;
+//   2. attention backward + GRU cell backward on its columns (same arithmetic as k_step_bwd, head.hip);
+//   3. its columns of dgi / dgh / dS, its entries of d(attention w), and its share of the previous clip's row dots.
+// No float atomics; every sum has a fixed order.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct HbSlot {
+    const float* hn; const float* w_att; const float* alpha; const int* valid; const float* dhn_out; const float* mask;
+    const float* gates; const float* gh; const float* hprev;
+    float* dgi; float* dgh; float* dsprev; float* dw;
+    const float* dsprev_next; const float* dgh_next; const float* whh; const float* pd_in;
+    const float* dgi_x; const float* wih_x;
+    const float* ghr; const float* hn_prev; const float* alpha_prev; const int* valid_prev; float* pd_out;
+    int present, has_next, has_dx, has_prev;
+};
+struct HbGroup { HbSlot s[3]; };     // [0] layer 1 (+ dhn_out), [1] layer 0 (+ mask, dx through layer 1's input product), [2] coordinate GRU
+
+#define HB_BLD 10                    // LDS row stride of a staged 8-column weight slice: the 4 k-groups of a wave hit disjoint banks
+#define HB_SMEM_FLOATS (3 * 768 * HB_BLD + 96 + 13 * NT * 8 + 9 * NT + 2 * NT * 8 + NT)
+
+__global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*Bs)[768][HB_BLD] = (float (*)[768][HB_BLD])smem;              // [0] whh of slot 0, [1] whh of slot 1, [2] wih_x of slot 1
+    float* BsC = smem + 3 * 768 * HB_BLD;                                 // column g of the coordinate GRU's whh
+    float (*Red)[NT][8] = (float (*)[NT][8])(BsC + 96);                   // [13][32][8]
+    float* s_da = (float*)(Red + 13);                                     // [3][32]
+    float* s_al = s_da + 3 * NT;                                          // [3][32]
+    int* s_v = (int*)(s_al + 3 * NT);                                     // [3][32]
+    float (*s_dw)[NT][8] = (float (*)[NT][8])(s_al + 6 * NT);             // [2][32][8]  ds * tanh(hn) of slots 0, 1
+    float* s_dwc = (float*)(s_dw + 2);                                    // [32]        ... of slot 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+    const HbSlot& S0 = G.s[0]; const HbSlot& S1 = G.s[1]; const HbSlot& S2 = G.s[2];
+
+    // ---- stage this workgroup's weight columns; row dots and attention weights of the three slots
+    {
+        const float* Wp[3] = {S0.whh, S1.whh, S1.wih_x};
+        const bool live[3] = {S0.present && S0.has_next, S1.present && S1.has_next, S1.present && S1.has_dx};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (!live[p]) continue;
+            for (int idx = tid; idx < 768 * 2; idx += 1024) {
+                const int n = idx >> 1, half = idx & 1;
+                const float4 v = *(const float4*)(Wp[p] + (size_t)n * 256 + 8 * g + 4 * half);
+                float* d = &Bs[p][n][4 * half];
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+        if (S2.present && S2.has_next && tid < 96) BsC[tid] = S2.whh[tid * 32 + g];
+    }
+    if (tid < 3 * NT) {
+        const HbSlot& S = G.s[tid >> 5];
+        const int k = tid & 31;
+        float da = 0.f, al = 0.f; int v = 0;
+        if (S.present) {
+            v = S.valid[k]; al = S.alpha[k];
+            if (S.has_next) {
+#pragma unroll 8
+                for (int q = 0; q < HS_WGS; ++q) da += S.pd_in[q * NT + k];
+            }
+        }
+        s_da[tid] = v ? da : 0.f; s_al[tid] = al; s_v[tid] = v;
+    }
+    __syncthreads();
+
+    // ---- 1. products for this workgroup's columns.  MFMA 16x16x4: lane l supplies A[l & 15][k'] and B[k'][l & 15] for
+    //         k' = l >> 4, D[4 (l >> 4) + r][l & 15] comes back in register r.  A lane loads 4 consecutive k as one float4
+    //         (k = 16t + 4q + c for its k-group q), so step (t, c) covers k = 16t + c, 16t + 4 + c, 16t + 8 + c, 16t + 12 + c.
+    {
+        const int i = lane & 15, q = lane >> 4;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (wave < 12) {
+            const int pr = wave >> 2;
+            const bool live = pr == 0 ? (S0.present && S0.has_next) : (pr == 1 ? (S1.present && S1.has_next) : (S1.present && S1.has_dx));
+            if (live) {
+                const float* A = pr == 0 ? S0.dgh_next : (pr == 1 ? S1.dgh_next : S1.dgi_x);
+                const int kb = (wave & 3) * 192;
+                const float* a0p = A + (size_t)i * 768 + kb + 4 * q;
+                const float* a1p = a0p + 16 * 768;
+                float4 a0[12], a1[12];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) { a0[t] = *(const float4*)(a0p + 16 * t); a1[t] = *(const float4*)(a1p + 16 * t); }
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    if (t + 6 < 12) { a0[t + 6] = *(const float4*)(a0p + 16 * (t + 6)); a1[t + 6] = *(const float4*)(a1p + 16 * (t + 6)); }
+                    const float* bp = &Bs[pr][kb + 16 * t + 4 * q][i & 7];
+                    const float b0 = i < 8 ? bp[0] : 0.f, b1 = i < 8 ? bp[HB_BLD] : 0.f, b2 = i < 8 ? bp[2 * HB_BLD] : 0.f, b3 = i < 8 ? bp[3 * HB_BLD] : 0.f;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].x, b0, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].x, b0, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].y, b1, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].y, b1, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].z, b2, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].z, b2, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].w, b3, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].w, b3, acc1, 0, 0, 0);
+                }
+            }
+        } else if (wave == 12 && S2.present && S2.has_next) {   // coordinate GRU: K = 96, one column
+            const float* a0p = S2.dgh_next + (size_t)i * 96 + 4 * q;
+            const float* a1p = a0p + 16 * 96;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const float4 x0 = *(const float4*)(a0p + 16 * t), x1 = *(const float4*)(a1p + 16 * t);
+                const float* bp = &BsC[16 * t + 4 * q];
+                const float b0 = i == 0 ? bp[0] : 0.f, b1 = i == 0 ? bp[1] : 0.f, b2 = i == 0 ? bp[2] : 0.f, b3 = i == 0 ? bp[3] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, b0, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, b0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, b1, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, b1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, b2, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, b2, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, b3, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, b3, acc1, 0, 0, 0);
+            }
+        }
+        if (wave < 13 && i < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Red[wave][4 * q + r][i] = acc0[r]; Red[wave][16 + 4 * q + r][i] = acc1[r]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. attention backward + GRU cell backward on this workgroup's columns (arithmetic of k_step_bwd, head.hip)
+    const int slot = tid < 512 ? tid >> 8 : 2;
+    const bool el = tid < 512 ? G.s[slot].present != 0 : (tid < 512 + NT && S2.present);
+    const int H = slot == 2 ? 32 : 256;
+    const int k = slot == 2 ? tid - 512 : (tid & 255) >> 3, jj = slot == 2 ? 0 : tid & 7, j = slot == 2 ? g : 8 * g + jj;
+    float pd = 0.f;
+    if (el) {
+        const HbSlot& S = G.s[slot];
+        const size_t t = (size_t)k * H + j;
+        float gs = 0.f;
+        if (S.has_next) {
+            const int w0 = slot == 2 ? 12 : 4 * slot;
+            const float gsum = slot == 2 ? Red[12][k][0] : ((Red[w0][k][jj] + Red[w0 + 1][k][jj]) + Red[w0 + 2][k][jj]) + Red[w0 + 3][k][jj];
+            gs = gsum + S.dsprev_next[t];
+        }
+        const float* da = s_da + slot * NT; const float* alv = s_al + slot * NT; const int* vv = s_v + slot * NT;
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) if (vv[q]) dot += alv[q] * da[q];
+        const bool v = vv[k] != 0;
+        const float al = alv[k], ds = v ? al * (da[k] - dot) : 0.f;
+        const float hn = S.hn[t], th = hs_tanh(hn);
+        float dh = 0.f, dspass = gs;                         // state kept: the gradient passes through
+        if (v) {
+            dh = gs * al + ds * S.w_att[j] * (1.f - th * th);
+            if (S.dhn_out) dh += S.dhn_out[t];
+            dspass = 0.f;
+        }
+        if (slot == 2) s_dwc[k] = ds * th; else s_dw[slot][k][jj] = ds * th;
+        if (S.has_dx) {
+            const float dx = ((Red[8][k][jj] + Red[9][k][jj]) + Red[10][k][jj]) + Red[11][k][jj];
+            dh += S.mask ? dx * S.mask[t] : dx;
+        }
+        const float* gt = S.gates + (size_t)k * 3 * H;
+        const float r = gt[j], z = gt[H + j], n = gt[2 * H + j];
+        const float ghn = S.gh[(size_t)k * 3 * H + 2 * H + j];
+        const float h = S.hprev[t];
+        const float dn = dh * (1.f - z), dz = dh * (h - n);
+        const float dan = dn * (1.f - n * n), daz = dz * z * (1.f - z), dar = dan * ghn * r * (1.f - r);
+        float* a = S.dgi + (size_t)k * 3 * H; float* cg = S.dgh + (size_t)k * 3 * H;
+        a[j] = dar; a[H + j] = daz; a[2 * H + j] = dan;
+        cg[j] = dar; cg[H + j] = daz; cg[2 * H + j] = dan * r;
+        const float dsp = dspass + dh * z;
+        S.dsprev[t] = dsp;
+        if (S.has_prev) {                                    // this workgroup's share of the previous clip's row dots
+            const float* gr = S.ghr + (size_t)k * 3 * H;
+            const float ap = S.alpha_prev[k];
+            const float inva = (S.valid_prev[k] != 0 && ap != 0.f) ? 1.f / ap : 0.f;
+            pd = dsp * S.hn_prev[t] + inva * ((dar * gr[j] + daz * gr[H + j]) + dan * r * gr[2 * H + j]);
+        }
+    }
+    if (tid < 512) {                                         // the 8 columns of a track sit in 8 neighbouring lanes
+        pd += __shfl_xor(pd, 1, 64); pd += __shfl_xor(pd, 2, 64); pd += __shfl_xor(pd, 4, 64);
+    }
+    if (el && jj == 0 && G.s[slot].has_prev) G.s[slot].pd_out[g * NT + k] = pd;
+    __syncthreads();
+    // d(attention w) of this workgroup's columns: sum over the 32 tracks in track order
+    if (tid < 16) {
+        const int sl = tid >> 3, c = tid & 7;
+        if (G.s[sl].present) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc += s_dw[sl][q][c];
+            G.s[sl].dw[8 * g + c] += acc;
+        }
+    } else if (tid == 16 && S2.present) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc += s_dwc[q];
+        S2.dw[g] += acc;
+    }
+}
+
+/* desc: HOST array, 3 slots x 28 int64: slot 0 = GRU layer 1 (256 wide), slot 1 = GRU layer 0 (256 wide; receives the
+ * gradient of its dropout'd output through layer 1's input product), slot 2 = coordinate GRU (32 wide).  Per slot:
+ * [0] present [1] hn [2] attention w [3] alpha [4] valid [5] dhn_out (0 = none) [6] dropout mask (0 = none) [7] gates
+ * [8] gh [9] hprev [10] dgi out [11] dgh out [12] dsprev out f32[32,H] (element-wise part of the gradient of the state
+ * entering this clip) [13] dw accumulator f32[H] [14] has_next: the clip is not the last one, then [15] dsprev_next
+ * (the [12] of the next clip) [16] dgh_next f32[32,3H] [17] whh f32[3H,H] [18] pd_in f32[32,32] partial row dots written
+ * by the next clip's stage  [19] has_dx (slot 1), then [20] dgi_x f32[32,768] layer 1's dgi of this clip [21] wih_x
+ * [22] has_prev: the clip is not the first one, then [23] ghr f32[32,3H] (raw recurrent product of this clip, from
+ * eventad_head_stage_fwd) [24] hn_prev [25] alpha_prev [26] valid_prev [27] pd_out f32[32,32]. */
+extern "C" int eventad_head_stage_bwd(const int64_t* d, void* stream) {
+    if (!d) return EVAD_ERR_ARG;
+    HbGroup G;
+    bool any = false;
+    for (int i = 0; i < 3; ++i) {
+        const int64_t* q = d + 28 * i; HbSlot& S = G.s[i];
+        S.present = q[0] != 0;
+        S.hn = (const float*)q[1]; S.w_att = (const float*)q[2]; S.alpha = (const float*)q[3]; S.valid = (const int*)q[4];
+        S.dhn_out = (const float*)q[5]; S.mask = (const float*)q[6]; S.gates = (const float*)q[7]; S.gh = (const float*)q[8];
+        S.hprev = (const float*)q[9]; S.dgi = (float*)q[10]; S.dgh = (float*)q[11]; S.dsprev = (float*)q[12]; S.dw = (float*)q[13];
+        S.has_next = q[14] != 0; S.dsprev_next = (const float*)q[15]; S.dgh_next = (const float*)q[16]; S.whh = (const float*)q[17];
+        S.pd_in = (const float*)q[18]; S.has_dx = q[19] != 0; S.dgi_x = (const float*)q[20]; S.wih_x = (const float*)q[21];
+        S.has_prev = q[22] != 0; S.ghr = (const float*)q[23]; S.hn_prev = (const float*)q[24]; S.alpha_prev = (const float*)q[25];
+        S.valid_prev = (const int*)q[26]; S.pd_out = (float*)q[27];
+        if (!S.present) { S.has_next = S.has_dx = S.has_prev = 0; continue; }
+        any = true;
+        if (!S.hn || !S.w_att || !S.alpha || !S.valid || !S.gates || !S.gh || !S.hprev || !S.dgi || !S.dgh || !S.dsprev || !S.dw) return EVAD_ERR_ARG;
+        if (S.has_next && (!S.dsprev_next || !S.dgh_next || !S.whh || !S.pd_in || ((uintptr_t)S.whh & 15) || ((uintptr_t)S.dgh_next & 15))) return EVAD_ERR_ARG;
+        if (S.has_dx && (i != 1 || !S.dgi_x || !S.wih_x || ((uintptr_t)S.wih_x & 15) || ((uintptr_t)S.dgi_x & 15))) return EVAD_ERR_ARG;
+        if (S.has_prev && (!S.ghr || !S.hn_prev || !S.alpha_prev || !S.valid_prev || !S.pd_out)) return EVAD_ERR_ARG;
+    }
+    if (!any) return EVAD_OK;
+    static bool attr_set = false;
+    const int lds = (int)(HB_SMEM_FLOATS * sizeof(float));
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_head_stage_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return -2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_head_stage_bwd, dim3(HS_WGS), dim3(1024), lds, (hipStream_t)stream, G);
     return evad_last_error();
 }

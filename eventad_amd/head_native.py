@@ -28,6 +28,9 @@ _KEEP_SLABS = os.environ.get("EVENTAD_KEEP_SLABS", "0") == "1"
 # forward recurrence: one fused launch per clip stage (attention of the previous clip + recurrent products + cell,
 # csrc/headstage.hip) instead of a grouped GEMM and a cell+attention launch.  0 = the two-launch form (kept for A/B runs).
 _STAGE_FWD = os.environ.get("EVENTAD_HEAD_STAGE", "1") == "1"
+# backward recurrence likewise (needs the fused forward, which stores the raw recurrent products it reads): one launch per
+# clip stage instead of cell+attention backward, a grouped GEMM and the launch that sums its split-K slabs
+_STAGE_BWD = _STAGE_FWD and os.environ.get("EVENTAD_HEAD_STAGE_BWD", "1") == "1"
 
 
 class NativeHead:
@@ -82,6 +85,9 @@ class NativeHead:
                      ("GIC", 96), ("GHC", 96), ("GC", 96), ("dGI0", 768), ("dGH0", 768), ("dGI1", 768),
                      ("dGH1", 768), ("dGIC", 96), ("dGHC", 96)):
             w[k] = f(R, n)
+        for k, n in (("GHR0", 768), ("GHR1", 768), ("GHRC", 96)):      # raw recurrent products (no bias), for the fused backward stages
+            w[k] = f(R, n)
+        w["pd"] = f(3, 2, NT * NT)                                # per-workgroup partial row dots, [layer][stage parity]
         for k, n in (("S0", 256), ("S1", 256), ("SC", 32)):
             w[k] = f(R + NT, n)
         for k, n in (("H0n", 256), ("X1", 256), ("H1n", 256), ("HCn", 32), ("F1r", 256), ("dPre", 256),
@@ -220,26 +226,27 @@ class NativeHead:
         st = torch.cuda.current_stream().cuda_stream
         rows = lambda t, b: t[b * NT:(b + 1) * NT].data_ptr()
         for b in range(B + 1):
-            d = (ctypes.c_int64 * 54)()
+            d = (ctypes.c_int64 * 57)()
             if b < B:
                 prev = b > 0
-                d[0:18] = [1, rows(w["H0n"], b - 1) if prev else 0, rows(w["S0"], b - 1) if prev else 0,
+                d[0:19] = [1, rows(w["H0n"], b - 1) if prev else 0, rows(w["S0"], b - 1) if prev else 0,
                            rows(w["valid"], b - 1) if prev else 0, watt.data_ptr(), rows(w["AL0"], b - 1) if prev else 0,
                            rows(w["S0"], b), P[ev + "weight_hh_l0"].data_ptr(), P[ev + "bias_hh_l0"].data_ptr(),
                            rows(w["GI0"], b), 0, 0, 0, rows(w["GH0"], b), rows(w["G0"], b), rows(w["H0n"], b),
-                           rows(self.D1, b) if train else 0, rows(w["X1"], b)]
-                d[36:54] = [1, rows(w["HCn"], b - 1) if prev else 0, rows(w["SC"], b - 1) if prev else 0,
+                           rows(self.D1, b) if train else 0, rows(w["X1"], b), rows(w["GHR0"], b)]
+                d[38:57] = [1, rows(w["HCn"], b - 1) if prev else 0, rows(w["SC"], b - 1) if prev else 0,
                             rows(w["valid"], b - 1) if prev else 0, wattc.data_ptr(), rows(w["ALC"], b - 1) if prev else 0,
                             rows(w["SC"], b), P[co + "weight_hh_l0"].data_ptr(), P[co + "bias_hh_l0"].data_ptr(),
-                            rows(w["GIC"], b), 0, 0, 0, rows(w["GHC"], b), rows(w["GC"], b), rows(w["HCn"], b), 0, 0]
+                            rows(w["GIC"], b), 0, 0, 0, rows(w["GHC"], b), rows(w["GC"], b), rows(w["HCn"], b), 0, 0,
+                            rows(w["GHRC"], b)]
             if b >= 1:
                 q = b - 1
                 prev = q > 0
-                d[18:36] = [1, rows(w["H1n"], q - 1) if prev else 0, rows(w["S1"], q - 1) if prev else 0,
+                d[19:38] = [1, rows(w["H1n"], q - 1) if prev else 0, rows(w["S1"], q - 1) if prev else 0,
                             rows(w["valid"], q - 1) if prev else 0, watt.data_ptr(), rows(w["AL1"], q - 1) if prev else 0,
                             rows(w["S1"], q), P[ev + "weight_hh_l1"].data_ptr(), P[ev + "bias_hh_l1"].data_ptr(),
                             0, rows(w["X1"], q), P[ev + "weight_ih_l1"].data_ptr(), P[ev + "bias_ih_l1"].data_ptr(),
-                            rows(w["GH1"], q), rows(w["G1"], q), rows(w["H1n"], q), 0, 0]
+                            rows(w["GH1"], q), rows(w["G1"], q), rows(w["H1n"], q), 0, 0, rows(w["GHR1"], q)]
             call("eventad_head_stage_fwd", ctypes.cast(d, ctypes.c_void_p), st)
 
     # ----------------------------------------------------------------- backward
@@ -277,7 +284,9 @@ class NativeHead:
         # adds them while it loads (same order as the reduce kernel: same bits) instead of a reduce launch per stage.
         SL = 3                                                  # ceil(768 / 256)
         p1 = p0 = px = None                                    # slabs of dS1 / dS0 / dX1 from the previous stage
-        for b in range(B - 1, -2, -1):
+        if _STAGE_BWD:
+            self._backward_chain_fused(B, train)
+        for b in range(B - 1, -2 if not _STAGE_BWD else B - 1, -1):
             steps, gemms = [], []
             i1 = i0 = ix = None
             if b >= 0:
@@ -332,6 +341,43 @@ class NativeHead:
                    [[w["dGI0"], G[ev + "bias_ih_l0"], 768, 768], [w["dGH0"], G[ev + "bias_hh_l0"], 768, 768],
                     [w["dGI1"], G[ev + "bias_ih_l1"], 768, 768], [w["dGH1"], G[ev + "bias_hh_l1"], 768, 768],
                     [w["dGIC"], G[co + "bias_ih_l0"], 96, 96], [w["dGHC"], G[co + "bias_hh_l0"], 96, 96]], R)
+
+    def _backward_chain_fused(self, B, train):
+        """The reverse recurrence with one launch per stage (eventad_head_stage_bwd): stage b runs GRU layer 1 and the
+        coordinate GRU on clip b and GRU layer 0 on clip b+1.  A stage first forms, for its columns, the products that
+        carry the previous stage's gate gradients to this clip's state (and, for layer 0, to its dropout'd output), then
+        does attention + cell backward; the attention's row dots come from partial dots the previous stage left."""
+        w, P = self.w, self.P
+        ev, co = "gru_net_event.gru.", "gru_net_cor.gru."
+        watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
+        st = torch.cuda.current_stream().cuda_stream
+        rows = lambda t, b: t[b * NT:(b + 1) * NT].data_ptr()
+        dS1, dS0, dSC = (w["dS1a"], w["dS1b"]), (w["dS0a"], w["dS0b"]), (w["dSCa"], w["dSCb"])
+        pd = w["pd"]
+
+        def slot(c, hn, wa, al, dhn_out, mask, gates, gh, hprev, dgi, dgh, dS, dw, whh, li, ghr, dgi_x=None, wih_x=None):
+            nxt, prv = c + 1 < B, c >= 1
+            return [1, rows(hn, c), wa.data_ptr(), rows(al, c), rows(w["valid"], c), rows(dhn_out, c) if dhn_out is not None else 0,
+                    rows(mask, c) if mask is not None else 0, rows(gates, c), rows(gh, c), rows(hprev, c), rows(dgi, c), rows(dgh, c),
+                    dS[c % 2].data_ptr(), dw.data_ptr(),
+                    int(nxt), dS[(c + 1) % 2].data_ptr() if nxt else 0, rows(dgh, c + 1) if nxt else 0, whh.data_ptr() if nxt else 0,
+                    pd[li, (c + 1) % 2].data_ptr() if nxt else 0,
+                    int(dgi_x is not None), rows(dgi_x, c) if dgi_x is not None else 0, wih_x.data_ptr() if wih_x is not None else 0,
+                    int(prv), rows(ghr, c) if prv else 0, rows(hn, c - 1) if prv else 0, rows(al, c - 1) if prv else 0,
+                    rows(w["valid"], c - 1) if prv else 0, pd[li, c % 2].data_ptr() if prv else 0]
+
+        for b in range(B - 1, -2, -1):
+            d = (ctypes.c_int64 * 84)()
+            if b >= 0:
+                d[0:28] = slot(b, w["H1n"], watt, w["AL1"], w["dH1o"], None, w["G1"], w["GH1"], w["S1"], w["dGI1"], w["dGH1"], dS1,
+                               w["dwatt1"], P[ev + "weight_hh_l1"], 0, w["GHR1"])
+                d[56:84] = slot(b, w["HCn"], wattc, w["ALC"], w["dHCo"], None, w["GC"], w["GHC"], w["SC"], w["dGIC"], w["dGHC"], dSC,
+                                w["dwattc"], P[co + "weight_hh_l0"], 2, w["GHRC"])
+            if b + 1 < B:
+                d[28:56] = slot(b + 1, w["H0n"], watt, w["AL0"], None, self.D1 if train else None, w["G0"], w["GH0"], w["S0"],
+                                w["dGI0"], w["dGH0"], dS0, w["dwatt0"], P[ev + "weight_hh_l0"], 1, w["GHR0"],
+                                dgi_x=w["dGI1"], wih_x=P[ev + "weight_ih_l1"])
+            call("eventad_head_stage_bwd", ctypes.cast(d, ctypes.c_void_p), st)
 
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self):

@@ -235,14 +235,27 @@ int eventad_gru_att_bwd_group(int n_prob, const int64_t* desc, void* stream);
  * recurrent products state . Whh^T of up to three GRU layers -- and, for slot 1, the input product -- for the
  * workgroup's hidden columns (fp32 MFMA), and the GRU cell (EventAD.py:62-97; gate order r,z,n).  Replaces the pair
  * eventad_gemm_group + eventad_gru_att_fwd_group per clip; the buffers it fills are the ones eventad_gru_att_bwd_group reads.
- * desc = HOST array, 3 slots x 18 int64: slot 0 = 256-wide layer, input product gi (incl. bias) precomputed; slot 1 =
+ * desc = HOST array, 3 slots x 19 int64: slot 0 = 256-wide layer, input product gi (incl. bias) precomputed; slot 1 =
  * 256-wide layer, input product xin . wih^T + bih computed here; slot 2 = 32-wide layer, gi precomputed.  Per slot:
  * [0] present [1] hn_prev f32[32,H] cell output of the previous clip (0 = none: the state is read from [6] as it is)
  * [2] s_prev f32[32,H] state that entered the previous clip (kept for invalid tracks) [3] valid_prev i32[32]
  * [4] attention w f32[H] [5] alpha_prev out f32[32] [6] s_cur f32[32,H] state entering this clip (out unless [1] = 0)
  * [7] whh f32[3H,H] [8] bhh [9] gi f32[32,3H] [10] xin f32[32,H] [11] wih f32[3H,H] [12] bih [13] gh out f32[32,3H]
- * [14] gates out f32[32,3H] [15] hn out f32[32,H] [16] dropout mask (0 = none) [17] xdrop out = hn * mask (0 = none). */
+ * [14] gates out f32[32,3H] [15] hn out f32[32,H] [16] dropout mask (0 = none) [17] xdrop out = hn * mask (0 = none)
+ * [18] ghr out f32[32,3H] = state . whh^T without the bias (0 = none; eventad_head_stage_bwd reads it). */
 int eventad_head_stage_fwd(const int64_t* desc, void* stream);
+/* Backward of one clip stage in ONE launch (32 workgroups x 1024 threads, 107 KB of LDS): for its 8 hidden columns a
+ * workgroup forms the products dgh_next . whh (gradient of the state entering the next clip) and -- GRU layer 0 -- dgi_x . wih_x
+ * (gradient of its dropout'd output) with fp32 MFMA, then does attention backward and GRU cell backward (arithmetic of
+ * eventad_gru_att_bwd_group).  The attention needs per-track dot products over whole rows of a product no workgroup
+ * holds completely: the stage that produced dgh_next leaves per-workgroup partial dots (pd), using the forward's raw
+ * recurrent products (ghr).  Replaces eventad_gru_att_bwd_group + eventad_gemm_group + the slab reduce per clip.
+ * desc = HOST array, 3 slots x 28 int64: slot 0 = GRU layer 1, slot 1 = GRU layer 0, slot 2 = coordinate GRU.  Per slot:
+ * [0] present [1] hn [2] attention w [3] alpha [4] valid [5] dhn_out (0 = none) [6] dropout mask (0 = none) [7] gates
+ * [8] gh [9] hprev [10] dgi out [11] dgh out [12] dsprev out f32[32,H] [13] dw accumulator f32[H] [14] has_next
+ * [15] dsprev_next [16] dgh_next f32[32,3H] [17] whh [18] pd_in f32[32,32] [19] has_dx (slot 1 only) [20] dgi_x f32[32,768]
+ * [21] wih_x [22] has_prev [23] ghr f32[32,3H] [24] hn_prev [25] alpha_prev [26] valid_prev [27] pd_out f32[32,32]. */
+int eventad_head_stage_bwd(const int64_t* desc, void* stream);
 /* Up to 8 independent small GEMMs per launch (one workgroup per 32x32 tile, its 4 waves split K in 64-deep
  * chunks and are summed in wave order = deterministic).  desc = HOST array, 16 int64 per problem: [0] A [1] B
  * [2] part scratch f32[ceil(K/256)][M][N] (only when K > 256) [3] C [4] bias(0=none) [5] lda [6] ldb [7] ldc [8] M [9] N [10] K
