@@ -121,7 +121,7 @@ def cpu_baseline(raw, sd, head_sd, W, H, B, steps=10, warmup=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")

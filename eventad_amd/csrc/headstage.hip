@@ -323,6 +323,20 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
     const HbSlot& S0 = G.s[0]; const HbSlot& S1 = G.s[1]; const HbSlot& S2 = G.s[2];
 
+    // ---- the first half of each MFMA wave's A rows is requested before anything else (it arrives while the weight slices
+    //      are staged); the second half is requested under the first half's MFMAs
+    const int mi = lane & 15, mq = lane >> 4;
+    const int mpr = wave >> 2;
+    const bool mlive = wave < 12 && (mpr == 0 ? (S0.present && S0.has_next) : (mpr == 1 ? (S1.present && S1.has_next) : (S1.present && S1.has_dx)));
+    const float* a0p = nullptr; const float* a1p = nullptr;
+    float4 a0[12], a1[12];
+    if (mlive) {
+        const float* A = mpr == 0 ? S0.dgh_next : (mpr == 1 ? S1.dgh_next : S1.dgi_x);
+        a0p = A + (size_t)mi * 768 + (wave & 3) * 192 + 4 * mq;
+        a1p = a0p + 16 * 768;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { a0[t] = *(const float4*)(a0p + 16 * t); a1[t] = *(const float4*)(a1p + 16 * t); }
+    }
     // ---- stage this workgroup's weight columns; row dots and attention weights of the three slots
     {
         const float* Wp[3] = {S0.whh, S1.whh, S1.wih_x};
@@ -354,6 +368,31 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
     }
     __syncthreads();
 
+    // ---- operands of the element-wise phase: requested now, consumed after the products
+    const int slot = tid < 512 ? tid >> 8 : 2;
+    const bool el = tid < 512 ? G.s[slot].present != 0 : (tid < 512 + NT && S2.present);
+    const int H = slot == 2 ? 32 : 256;
+    const int k = slot == 2 ? tid - 512 : (tid & 255) >> 3, jj = slot == 2 ? 0 : tid & 7, j = slot == 2 ? g : 8 * g + jj;
+    float e_hn = 0.f, e_w = 0.f, e_dho = 0.f, e_mask = 1.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_ghn = 0.f, e_hp = 0.f, e_dsn = 0.f;
+    float e_gr[3] = {0.f, 0.f, 0.f}, e_hnp = 0.f, e_ap = 0.f; int e_vp = 0;
+    if (el) {
+        const HbSlot& S = G.s[slot];
+        const size_t t = (size_t)k * H + j;
+        e_hn = S.hn[t]; e_w = S.w_att[j];
+        if (S.dhn_out) e_dho = S.dhn_out[t];
+        if (S.has_dx && S.mask) e_mask = S.mask[t];
+        const float* gt = S.gates + (size_t)k * 3 * H;
+        e_r = gt[j]; e_z = gt[H + j]; e_n = gt[2 * H + j];
+        e_ghn = S.gh[(size_t)k * 3 * H + 2 * H + j];
+        e_hp = S.hprev[t];
+        if (S.has_next) e_dsn = S.dsprev_next[t];
+        if (S.has_prev) {
+            const float* gr = S.ghr + (size_t)k * 3 * H;
+            e_gr[0] = gr[j]; e_gr[1] = gr[H + j]; e_gr[2] = gr[2 * H + j];
+            e_hnp = S.hn_prev[t]; e_ap = S.alpha_prev[k]; e_vp = S.valid_prev[k];
+        }
+    }
+
     // ---- 1. products for this workgroup's columns.  MFMA 16x16x4: lane l supplies A[l & 15][k'] and B[k'][l & 15] for
     //         k' = l >> 4, D[4 (l >> 4) + r][l & 15] comes back in register r.  A lane loads 4 consecutive k as one float4
     //         (k = 16t + 4q + c for its k-group q), so step (t, c) covers k = 16t + c, 16t + 4 + c, 16t + 8 + c, 16t + 12 + c.
@@ -361,16 +400,9 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
         const int i = lane & 15, q = lane >> 4;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (wave < 12) {
-            const int pr = wave >> 2;
-            const bool live = pr == 0 ? (S0.present && S0.has_next) : (pr == 1 ? (S1.present && S1.has_next) : (S1.present && S1.has_dx));
-            if (live) {
-                const float* A = pr == 0 ? S0.dgh_next : (pr == 1 ? S1.dgh_next : S1.dgi_x);
+            const int pr = mpr;
+            if (mlive) {
                 const int kb = (wave & 3) * 192;
-                const float* a0p = A + (size_t)i * 768 + kb + 4 * q;
-                const float* a1p = a0p + 16 * 768;
-                float4 a0[12], a1[12];
-#pragma unroll
-                for (int t = 0; t < 6; ++t) { a0[t] = *(const float4*)(a0p + 16 * t); a1[t] = *(const float4*)(a1p + 16 * t); }
 #pragma unroll
                 for (int t = 0; t < 12; ++t) {
                     if (t + 6 < 12) { a0[t + 6] = *(const float4*)(a0p + 16 * (t + 6)); a1[t + 6] = *(const float4*)(a1p + 16 * (t + 6)); }
@@ -404,10 +436,6 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
     __syncthreads();
 
     // ---- 2. attention backward + GRU cell backward on this workgroup's columns (arithmetic of k_step_bwd, head.hip)
-    const int slot = tid < 512 ? tid >> 8 : 2;
-    const bool el = tid < 512 ? G.s[slot].present != 0 : (tid < 512 + NT && S2.present);
-    const int H = slot == 2 ? 32 : 256;
-    const int k = slot == 2 ? tid - 512 : (tid & 255) >> 3, jj = slot == 2 ? 0 : tid & 7, j = slot == 2 ? g : 8 * g + jj;
     float pd = 0.f;
     if (el) {
         const HbSlot& S = G.s[slot];
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
         if (S.has_next) {
             const int w0 = slot == 2 ? 12 : 4 * slot;
             const float gsum = slot == 2 ? Red[12][k][0] : ((Red[w0][k][jj] + Red[w0 + 1][k][jj]) + Red[w0 + 2][k][jj]) + Red[w0 + 3][k][jj];
-            gs = gsum + S.dsprev_next[t];
+            gs = gsum + e_dsn;
         }
         const float* da = s_da + slot * NT; const float* alv = s_al + slot * NT; const int* vv = s_v + slot * NT;
         float dot = 0.f;
@@ -424,22 +452,19 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
         for (int q = 0; q < NT; ++q) if (vv[q]) dot += alv[q] * da[q];
         const bool v = vv[k] != 0;
         const float al = alv[k], ds = v ? al * (da[k] - dot) : 0.f;
-        const float hn = S.hn[t], th = hs_tanh(hn);
+        const float hn = e_hn, th = hs_tanh(hn);
         float dh = 0.f, dspass = gs;                         // state kept: the gradient passes through
         if (v) {
-            dh = gs * al + ds * S.w_att[j] * (1.f - th * th);
-            if (S.dhn_out) dh += S.dhn_out[t];
+            dh = gs * al + ds * e_w * (1.f - th * th);
+            dh += e_dho;
             dspass = 0.f;
         }
         if (slot == 2) s_dwc[k] = ds * th; else s_dw[slot][k][jj] = ds * th;
         if (S.has_dx) {
             const float dx = ((Red[8][k][jj] + Red[9][k][jj]) + Red[10][k][jj]) + Red[11][k][jj];
-            dh += S.mask ? dx * S.mask[t] : dx;
+            dh += dx * e_mask;
         }
-        const float* gt = S.gates + (size_t)k * 3 * H;
-        const float r = gt[j], z = gt[H + j], n = gt[2 * H + j];
-        const float ghn = S.gh[(size_t)k * 3 * H + 2 * H + j];
-        const float h = S.hprev[t];
+        const float r = e_r, z = e_z, n = e_n, ghn = e_ghn, h = e_hp;
         const float dn = dh * (1.f - z), dz = dh * (h - n);
         const float dan = dn * (1.f - n * n), daz = dz * z * (1.f - z), dar = dan * ghn * r * (1.f - r);
         float* a = S.dgi + (size_t)k * 3 * H; float* cg = S.dgh + (size_t)k * 3 * H;
@@ -448,10 +473,8 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
         const float dsp = dspass + dh * z;
         S.dsprev[t] = dsp;
         if (S.has_prev) {                                    // this workgroup's share of the previous clip's row dots
-            const float* gr = S.ghr + (size_t)k * 3 * H;
-            const float ap = S.alpha_prev[k];
-            const float inva = (S.valid_prev[k] != 0 && ap != 0.f) ? 1.f / ap : 0.f;
-            pd = dsp * S.hn_prev[t] + inva * ((dar * gr[j] + daz * gr[H + j]) + dan * r * gr[2 * H + j]);
+            const float inva = (e_vp != 0 && e_ap != 0.f) ? 1.f / e_ap : 0.f;
+            pd = dsp * e_hnp + inva * ((dar * e_gr[0] + daz * e_gr[1]) + dan * r * e_gr[2]);
         }
     }
     if (tid < 512) {                                         // the 8 columns of a track sit in 8 neighbouring lanes
