@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
 # C-ABI call -> prefixes of the kernel names it launches, as they appear in the rocprofv3 traces / profiles/*_hbm_traffic.json
 # (the template arguments depend on the configuration: row scan or spiral walk, LUT fully or partly in LDS)
-KERNEL_OF = {"eventad_build_ell#1": ("k_build_ell_rowscan", "k_build_ell_reg"), "eventad_l1_conv1#1": ("k_l1_conv<20",),
+KERNEL_OF = {"eventad_build_ell#1": ("k_build_ell_rowscan", "k_build_ell_reg", "k_build_ell_pix"), "eventad_l1_conv1#1": ("k_l1_conv<20",),
              "eventad_l1_conv2#1": ("k_l1_conv<16",), "eventad_pool_seg0#1": ("k_pool_seg0(", "k_pool_seg0")}
 
 
