@@ -62,6 +62,8 @@ class NativeHead:
                                                            # autograd would add the bridge's result onto itself)
             self.P[name], self.G[name] = v, g
         self._B = None
+        # launch form of the clip recurrence: one fused launch per stage (default) or the older two / three launches per stage
+        self.stage_fwd, self.stage_bwd = _STAGE_FWD, _STAGE_BWD
         self.keep_superseded_workspaces = False               # set once a hipGraph holds pointers into the workspace
         self._retired_ws = []
 
@@ -182,10 +184,12 @@ class NativeHead:
         # coordinate GRU on clip b and GRU layer 1 on clip b-1 (its input, the dropout'd layer-0 output of clip
         # b-1, and its state, the layer-1 attention of clip b-2, are both a stage old), so one stage is two
         # dependent launches -- a grouped GEMM and a fused cell+attention -- instead of five.
-        if _STAGE_FWD:
+        fused_fwd = self.stage_fwd
+        self._fw_fused = fused_fwd
+        if fused_fwd:
             self._gg(*input_proj)
             self._forward_chain_fused(B, train)
-        for b in range(0 if _STAGE_FWD else B + 1):
+        for b in range(0 if fused_fwd else B + 1):
             gemms, steps = (list(input_proj) if b == 0 else []), []
             if b < B:
                 r0, r1 = b * NT, (b + 1) * NT
@@ -284,9 +288,10 @@ class NativeHead:
         # adds them while it loads (same order as the reduce kernel: same bits) instead of a reduce launch per stage.
         SL = 3                                                  # ceil(768 / 256)
         p1 = p0 = px = None                                    # slabs of dS1 / dS0 / dX1 from the previous stage
-        if _STAGE_BWD:
+        fused_bwd = self.stage_bwd and self._fw_fused         # the fused backward reads what only the fused forward stores
+        if fused_bwd:
             self._backward_chain_fused(B, train)
-        for b in range(B - 1, -2 if not _STAGE_BWD else B - 1, -1):
+        for b in range(B - 1, -2 if not fused_bwd else B - 1, -1):
             steps, gemms = [], []
             i1 = i0 = ix = None
             if b >= 0:

@@ -27,8 +27,14 @@ def _data(case):
     return d
 
 
+# launch form of the clip recurrence: "stage" = one fused launch per clip stage forward and backward (the default),
+# "stage_fwd" = fused forward, three launches per stage backward, "launches" = two / three launches per stage
+FORMS = {"stage": (True, True), "stage_fwd": (True, False), "launches": (False, False)}
+
+
+@pytest.mark.parametrize("form", list(FORMS))
 @pytest.mark.parametrize("name", CASES)
-def test_native_head_matches_reference_golden_and_autograd(name, golden_dir):
+def test_native_head_matches_reference_golden_and_autograd(name, form, golden_dir):
     gold = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
     kw = gold["kw"]
     m = _model(kw["seed"])
@@ -36,6 +42,7 @@ def test_native_head_matches_reference_golden_and_autograd(name, golden_dir):
     feats = gold["feats"].cuda()
     labels = data.bbox[:, 4]
     nh = m.native_head()
+    nh.stage_fwd, nh.stage_bwd = FORMS[form]
     loss, logits, valid, targets = nh.forward(feats, data.bbox, data.bbox_batch, labels, data.num_graphs, 256, 256, False)
     got = logits[valid].cpu()
     assert got.shape == gold["logits"].shape
@@ -141,6 +148,34 @@ def test_grouped_tile_gemm():
     call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
     for pr, ref, shp in zip(probs, refs, shapes):
         assert torch.allclose(pr[3], ref, atol=2e-4, rtol=1e-4), (shp, float((pr[3] - ref).abs().max()))
+
+
+def test_launch_forms_agree_with_dropout_active():
+    """Training mode (GRU inter-layer dropout + fusion dropout, same seeded masks): the fused stage kernels and the
+    separate launches give the same loss and gradients up to the order of the sums."""
+    kw = dict(seed=17, num_graphs=8, tracks=10, nodes_per_clip=35, drop_prob=0.2, empty_clip=3, far_box=True)
+    m = _model(17).train()
+    data = _data(make_head_case(**kw))
+    feats = torch.randn(8, 2, 31, 64, generator=torch.Generator().manual_seed(6)).cuda()
+    feats[3] = 0                                                  # a clip without any valid track: its state passes through
+    labels = data.bbox[:, 4]
+    nh = m.native_head()
+    out = {}
+    for form, (f, b) in FORMS.items():
+        nh.stage_fwd, nh.stage_bwd = f, b
+        torch.manual_seed(123)
+        loss, logits, valid, _ = nh.forward(feats, data.bbox, data.bbox_batch, labels, 8, 256, 256, True)
+        nh.backward()
+        torch.cuda.synchronize()
+        out[form] = (float(loss), logits.clone(), valid.clone(), {k: v.clone() for k, v in nh.G.items()})
+    ref = out["launches"]
+    assert int(ref[2].sum()) > 20 and ref[0] > 0
+    for form in ("stage", "stage_fwd"):
+        got = out[form]
+        assert abs(got[0] - ref[0]) < 1e-5 * max(1.0, ref[0]) and torch.equal(got[2], ref[2])
+        assert torch.allclose(got[1], ref[1], atol=1e-5, rtol=1e-5)
+        for k in ref[3]:
+            assert torch.allclose(got[3][k], ref[3][k], atol=2e-5, rtol=2e-4), (form, k)
 
 
 def test_native_head_large_batch_matches_autograd():
