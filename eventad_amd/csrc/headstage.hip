@@ -27,6 +27,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float hs_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float hs_tanh(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
 
+// More than 64 KB of dynamic LDS has to be allowed per kernel and per device, once.
+static int hs_allow_lds(const void* kernel, int bytes, int which) {
+    static bool done[2][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return -2; }
+    if (!done[which][dev]) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        done[which][dev] = true;
+    }
+    return 0;
+}
+
 struct HsSlot {
     const float* hn_prev; const float* s_prev; const int* valid_prev; const float* w_att; float* alpha_prev; float* s_cur;
     const float* whh; const float* bhh; const float* gi; const float* xin; const float* wih; const float* bih;
@@ -265,15 +277,8 @@ extern "C" int eventad_head_stage_fwd(const int64_t* d, void* stream) {
         if (((uintptr_t)S.whh & 15) || (i == 1 && ((uintptr_t)S.wih & 15))) return EVAD_ERR_ARG;
     }
     if (!any) return EVAD_OK;
-    static bool attr_set = false;
     const int lds = (int)(HS_SMEM_FLOATS * sizeof(float));
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_head_stage_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return -2;
-        }
-        attr_set = true;
-    }
+    if (hs_allow_lds((const void*)k_head_stage_fwd, lds, 0)) return -2;
     hipLaunchKernelGGL(k_head_stage_fwd, dim3(HS_WGS), dim3(1024), lds, (hipStream_t)stream, G);
     return evad_last_error();
 }
@@ -530,15 +535,8 @@ extern "C" int eventad_head_stage_bwd(const int64_t* d, void* stream) {
         if (S.has_prev && (!S.ghr || !S.hn_prev || !S.alpha_prev || !S.valid_prev || !S.pd_out)) return EVAD_ERR_ARG;
     }
     if (!any) return EVAD_OK;
-    static bool attr_set = false;
     const int lds = (int)(HB_SMEM_FLOATS * sizeof(float));
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_head_stage_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return -2;
-        }
-        attr_set = true;
-    }
+    if (hs_allow_lds((const void*)k_head_stage_bwd, lds, 1)) return -2;
     hipLaunchKernelGGL(k_head_stage_bwd, dim3(HS_WGS), dim3(1024), lds, (hipStream_t)stream, G);
     return evad_last_error();
 }
