@@ -274,16 +274,23 @@ extern "C" int eventad_gru_att_bwd_group(int n, const int64_t* d, void* stream) 
 // is the order of the reference's `losses['cross_entropy'] += loss`.
 __global__ void k_fuse_out(const float* __restrict__ F1r, const float* __restrict__ D2, const float* __restrict__ Wo,
                            const float* __restrict__ bo, const int* __restrict__ target, const int* __restrict__ valid,
-                           int R, float* __restrict__ logits, float* __restrict__ dlog, float* __restrict__ loss_rows) {
+                           int R, float* __restrict__ logits, float* __restrict__ dlog, float* __restrict__ loss_rows,
+                           float* __restrict__ dPre) {
     int row = blockIdx.x, lane = threadIdx.x;
     if (row >= R) return;
     float a0 = 0.f, a1 = 0.f;
-    for (int j = lane; j < 256; j += 64) {
-        float f = F1r[(size_t)row * 256 + j];
-        if (D2) f *= D2[(size_t)row * 256 + j];
-        a0 += f * Wo[j]; a1 += f * Wo[256 + j];
+    float fr[4], dm[4], w0[4], w1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+        fr[i] = F1r[(size_t)row * 256 + j];
+        dm[i] = D2 ? D2[(size_t)row * 256 + j] : 1.f;
+        w0[i] = Wo[j]; w1[i] = Wo[256 + j];
+        const float f = D2 ? fr[i] * dm[i] : fr[i];
+        a0 += f * w0[i]; a1 += f * w1[i];
     }
     for (int d = 32; d > 0; d >>= 1) { a0 += __shfl_down(a0, d, 64); a1 += __shfl_down(a1, d, 64); }
+    float g0 = 0.f, g1 = 0.f;
     if (lane == 0) {
         float l0 = a0 + bo[0], l1 = a1 + bo[1];
         logits[2 * row] = l0; logits[2 * row + 1] = l1;
@@ -291,8 +298,15 @@ __global__ void k_fuse_out(const float* __restrict__ F1r, const float* __restric
         int t = target[row], v = valid[row];
         float lse = logf(s) + m;
         loss_rows[row] = v ? lse - (t ? l1 : l0) : 0.f;
-        dlog[2 * row] = v ? e0 / s - (t == 0 ? 1.f : 0.f) : 0.f;
-        dlog[2 * row + 1] = v ? e1 / s - (t == 1 ? 1.f : 0.f) : 0.f;
+        g0 = v ? e0 / s - (t == 0 ? 1.f : 0.f) : 0.f;
+        g1 = v ? e1 / s - (t == 1 ? 1.f : 0.f) : 0.f;
+        dlog[2 * row] = g0; dlog[2 * row + 1] = g1;
+    }
+    if (dPre) {      // backward of the output layer into the hidden layer, while the row is in registers (= k_out_bwd_pre)
+        g0 = __shfl(g0, 0, 64); g1 = __shfl(g1, 0, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dPre[(size_t)row * 256 + lane + 64 * i] = fr[i] > 0.f ? (g0 * w0[i] + g1 * w1[i]) * dm[i] : 0.f;
     }
 }
 
@@ -310,9 +324,9 @@ __global__ __launch_bounds__(256) void k_loss_sum(const float* __restrict__ loss
 
 extern "C" int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
                                 const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss,
-                                void* stream) {
+                                float* dPre, void* stream) {
     if (!F1r || !Wo || !bo || !target || !valid || !logits || !dlog || !loss_rows || !loss || R <= 0) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_fuse_out, dim3(R), dim3(64), 0, (hipStream_t)stream, F1r, D2, Wo, bo, target, valid, R, logits, dlog, loss_rows);
+    hipLaunchKernelGGL(k_fuse_out, dim3(R), dim3(64), 0, (hipStream_t)stream, F1r, D2, Wo, bo, target, valid, R, logits, dlog, loss_rows, dPre);
     hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, R, loss);
     return evad_last_error();
 }
@@ -331,7 +345,8 @@ __global__ void k_out_bwd_pre(const float* __restrict__ dlog, const float* __res
 
 __global__ __launch_bounds__(256) void k_out_bwd_w(const float* __restrict__ dlog, const float* __restrict__ F1r,
                                                    const float* __restrict__ D2, int R, float* __restrict__ dWo,
-                                                   float* __restrict__ dbo) {
+                                                   float* __restrict__ dbo, float* __restrict__ clear, int n_clear) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_clear; i += 64 * 256) clear[i] = 0.f;
     int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;       // 64 blocks x 4 waves = 256 columns
     float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
     for (int r = lane; r < R; r += 64) {
@@ -344,11 +359,12 @@ __global__ __launch_bounds__(256) void k_out_bwd_w(const float* __restrict__ dlo
 }
 
 extern "C" int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
-                               float* dWo, float* dbo, void* stream) {
-    if (!dlog || !Wo || !F1r || !dPre || !dWo || !dbo || R <= 0) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_out_bwd_pre, dim3(evad_blocks((long long)R * 256, 256)), dim3(256), 0, (hipStream_t)stream, dlog, Wo,
-                       F1r, D2, R, dPre);
-    hipLaunchKernelGGL(k_out_bwd_w, dim3(64), dim3(256), 0, (hipStream_t)stream, dlog, F1r, D2, R, dWo, dbo);
+                               float* dWo, float* dbo, float* clear, int n_clear, void* stream) {
+    if (!dlog || !Wo || !F1r || !dWo || !dbo || R <= 0 || n_clear < 0 || (n_clear > 0 && !clear)) return EVAD_ERR_ARG;
+    if (dPre)
+        hipLaunchKernelGGL(k_out_bwd_pre, dim3(evad_blocks((long long)R * 256, 256)), dim3(256), 0, (hipStream_t)stream, dlog, Wo,
+                           F1r, D2, R, dPre);
+    hipLaunchKernelGGL(k_out_bwd_w, dim3(64), dim3(256), 0, (hipStream_t)stream, dlog, F1r, D2, R, dWo, dbo, clear, n_clear);
     return evad_last_error();
 }
 

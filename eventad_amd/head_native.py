@@ -151,8 +151,15 @@ class NativeHead:
              torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train, lean=False):
+    @staticmethod
+    def fill_masks(masks):
+        """Dropout masks of one step (GRU inter-layer | fusion MLP, keep probability 0.7, pre-scaled) into `masks`
+        f32[2*B*32, 256]: two launches that depend on nothing, so a pipelined caller can issue them ahead of the head."""
+        return masks.bernoulli_(0.7).div_(0.7)
+
+    def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train, lean=False, masks=None):
         """feats f32[B,2,31,64] (ROI features), bbox f32[M,6], bbox_batch i64[M], labels f32[M] or None.
+        masks: this step's dropout masks, already drawn by fill_masks (default: drawn here, when train).
         Returns (loss 0-d, logits [B,32,2], valid bool[B,32], targets i64[B,32]); keeps what backward needs."""
         self._alloc(B)
         w, P = self.w, self.P
@@ -172,8 +179,9 @@ class NativeHead:
              ptr(w["X"]), ptr(w["CO"]), ptr(w["target"]), ptr(w["valid"]), st)
         self.D1 = self.D2 = None
         if train:                                              # nn.GRU(dropout=.3) between layers; fusion Dropout(.3):
-            w["D"].bernoulli_(0.7).div_(0.7)                   # both masks in two launches
-            self.D1, self.D2 = w["D"][:R], w["D"][R:]
+            D = masks if masks is not None else self.fill_masks(w["D"])      # both masks in two launches
+            assert tuple(D.shape) == (2 * R, 256) and D.is_contiguous()
+            self.D1, self.D2 = D[:R], D[R:]
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
         # input projections of every clip at once: they ride in the first stage's launch (independent problems)
@@ -213,7 +221,8 @@ class NativeHead:
                  (0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, P[fu + "coord_proj.bias"]))
         self._gg((0, 1, w["ZCAT"], 512, P[fu + "fusion.0.weight"], 512, w["F1r"], 256, R, 256, 512, P[fu + "fusion.0.bias"], 1))
         call("eventad_fuse_out", ptr(w["F1r"]), _rp(self.D2), _rp(P[fu + "fusion.3.weight"]), _rp(P[fu + "fusion.3.bias"]),
-             ptr(w["target"]), ptr(w["valid"]), R, ptr(w["logits"]), ptr(w["dlog"]), ptr(w["loss_rows"]), ptr(w["loss"]), st)
+             ptr(w["target"]), ptr(w["valid"]), R, ptr(w["logits"]), ptr(w["dlog"]), ptr(w["loss_rows"]), ptr(w["loss"]),
+             ptr(w["dPre"]), st)                               # dPre: the first step of backward(), while the rows are in registers
         self._fw = (B, train)
         if lean:                                               # training loop: no dtype conversions (3 launches less)
             return (w["loss"][0], w["logits"].view(B, NT, 2), w["valid"].view(B, NT), w["target"].view(B, NT))
@@ -263,9 +272,8 @@ class NativeHead:
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
         # every used gradient entry is written (not accumulated) below; the attention vectors accumulate over the clips in
         # small buffers of their own (cleared here), the alignment pads of the flat buffer are zero from allocation
-        w["dwatt"].zero_()
-        call("eventad_out_bwd", ptr(w["dlog"]), _rp(P[fu + "fusion.3.weight"]), ptr(w["F1r"]), _rp(self.D2), R, ptr(w["dPre"]),
-             _rp(G[fu + "fusion.3.weight"]), _rp(G[fu + "fusion.3.bias"]), st)
+        call("eventad_out_bwd", ptr(w["dlog"]), _rp(P[fu + "fusion.3.weight"]), ptr(w["F1r"]), _rp(self.D2), R, None,
+             _rp(G[fu + "fusion.3.weight"]), _rp(G[fu + "fusion.3.bias"]), ptr(w["dwatt"]), w["dwatt"].numel(), st)
         dE, dC = w["dZCAT"], w["dZCAT"][:, 256:]
         self._gg((1, 0, w["dPre"], 256, w["ZCAT"], 512, G[fu + "fusion.0.weight"], 512, 256, 512, R),
                  (0, 0, w["dPre"], 256, P[fu + "fusion.0.weight"], 512, w["dZCAT"], 512, R, 512, 256))

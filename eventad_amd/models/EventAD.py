@@ -220,7 +220,7 @@ class EventADModel(nn.Module):
             object.__setattr__(self, "_nh", nh)
         return nh
 
-    def _head_native(self, feats, data, labels, lean=False):
+    def _head_native(self, feats, data, labels, lean=False, masks=None):
         from ..head_native import PARAMS
         nh = self.native_head()
         B = int(data.num_graphs)
@@ -230,7 +230,7 @@ class EventADModel(nn.Module):
             params = dict(self.named_parameters())
             return _NativeHeadFn.apply(nh, feats, bbox, bb, labels, B, W, H, self.training, *[params[n] for n, _ in PARAMS])
         if lean:                                               # TrainStep: results stay in the head's static buffers
-            return nh.forward(feats, bbox, bb, labels, B, W, H, self.training, lean=True)
+            return nh.forward(feats, bbox, bb, labels, B, W, H, self.training, lean=True, masks=masks)
         loss, logits, valid, targets = nh.forward(feats, bbox, bb, labels, B, W, H, self.training)
         return loss.clone(), logits, valid, targets
 

@@ -49,7 +49,7 @@ class TrainStep:
         # two-graph pipeline: CUs set aside for the head's stream.  The head is a chain of ~70 small dependent launches;
         # sharing CUs with the backbone's chip-wide grids, each of them queues behind whatever grid is being dispatched and
         # the chain stretches from 0.55 to 1.05 ms (C2) -- longer than the backbone graph.  -1 (default): decided at
-        # capture from the two graphs' stand-alone times (a head that is short against its backbone gets no CUs of its
+        # capture from the two graphs' stand-alone times (a head that takes less than 0.3 of its backbone's time gets no CUs of its
         # own: they would only be taken from the backbone); 0: never; n > 0: always n CUs.
         self.head_cus = int(os.environ.get("EVENTAD_HEAD_CUS", "-1"))
         # two-graph pipeline: number of backbone chains (each with its own workspace set, input buffers, feature buffer and
@@ -61,11 +61,12 @@ class TrainStep:
         self.backbone_chains = int(os.environ.get("EVENTAD_BACKBONE_CHAINS", "0"))
 
     # ------------------------------------------------------------------ pieces
-    def _head_update(self, feats, head_in, labels=None):
-        """Head forward + backward + gradient all-reduce + clip/AdamW on `feats`; -> (loss, grad_norm) device scalars."""
+    def _head_update(self, feats, head_in, labels=None, masks=None):
+        """Head forward + backward + gradient all-reduce + clip/AdamW on `feats`; -> (loss, grad_norm) device scalars.
+        masks: dropout masks drawn ahead of time (NativeHead.fill_masks), else they are drawn here."""
         if labels is None:
             labels = head_in.bbox[:, 4]
-        loss, _, _, _ = self.model._head_native(feats, head_in, labels, lean=True)
+        loss, _, _, _ = self.model._head_native(feats, head_in, labels, lean=True, masks=masks)
         self.nh.backward()
         norm = self.sync.reduce_and_update(self.nh.optimizer_step)
         return loss, norm
@@ -259,10 +260,17 @@ class TrainStep:
                         self.model.extract_features(in_b[c], frames=(1,))
                         torch.cuda.synchronize()
                 gb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                # the step's dropout masks depend on nothing: they are drawn at the end of the chain's backbone graph, off the
+                # head's chain of dependent launches
+                masks = None
+                if self.model.training:
+                    masks = torch.empty((2 * in_h[c].num_graphs * 32, 256), device=in_h[c].bbox.device)
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     feats = self.model.extract_features(in_b[c], frames=(1,))
+                    if masks is not None:
+                        self.nh.fill_masks(masks)
                 with torch.cuda.graph(gh, capture_error_mode="thread_local"):
-                    out = self._head_update(feats, in_h[c])
+                    out = self._head_update(feats, in_h[c], masks=masks)
                 if native is not None:
                     native.select_workspace(0)
             d["gb"].append(gb); d["gh"].append(gh); d["feats"].append(feats); d["out"].append(out)
@@ -281,7 +289,9 @@ class TrainStep:
                 torch.cuda.synchronize()
                 t.append(a.elapsed_time(b) / 3)
             d["graph_ms"] = tuple(t)
-            d["masked"] = t[1] > 0.5 * t[0]
+            # C2: head 0.41 ms against 0.82 ms (ratio 0.5; the partition + three chains give 0.68 ms per step against 0.88
+            # without); C3 / C4 / C5: ratios 0.16 / 0.02 / 0.03, where taking CUs from the backbone only costs
+            d["masked"] = t[1] > 0.3 * t[0]
         n = self.backbone_chains
         if n <= 0:
             n = 3 if (d["masked"] and native is not None and getattr(data, "image_feats", None) is not None) else 2

@@ -264,11 +264,15 @@ int eventad_head_stage_bwd(const int64_t* desc, void* stream);
  * by the last workgroup to reach the tile instead of by a second launch; the value 1 = leave the slabs of a K > 256
  * product un-summed in `part` for a consumer that adds them itself (eventad_gru_att_bwd_group does). */
 int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream);
-/* fusion[3] Linear(256,2) + summed cross-entropy (EventAD.py:27,280-281) and its backward. */
+/* fusion[3] Linear(256,2) + summed cross-entropy (EventAD.py:27,280-281) and its backward.  eventad_fuse_out with dPre
+ * non-NULL also writes dPre f32[R,256] = d loss / d (pre-activation of the hidden layer), which eventad_out_bwd then need
+ * not compute (pass its dPre = NULL); eventad_out_bwd also clears the n_clear floats at `clear` (nullable): accumulators
+ * that the stages after it add into. */
 int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
-                     const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss, void* stream);
+                     const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss, float* dPre,
+                     void* stream);
 int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
-                    float* dWo, float* dbo, void* stream);
+                    float* dWo, float* dbo, float* clear, int n_clear, void* stream);
 /* up to 8 column sums per launch; desc = HOST array, 4 int64 per problem: [0] A [1] out [2] lda [3] N */
 int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream);
 /* clip_grad_norm_ + AdamW on flat buffers (utils/train.py:27-53,141-152).  state f32[8]:
