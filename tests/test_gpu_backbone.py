@@ -187,6 +187,25 @@ def test_wave_per_pixel_edge_search_equals_the_walk_on_dense_input():
             assert torch.equal(a, b)
 
 
+def test_wave_per_pixel_edge_search_with_a_time_window_beyond_float_precision():
+    """delta_t >= 2^24 us: (float)(ts - t) > (float)delta_t is no longer the integer comparison, so the wave-per-pixel
+    search takes its float-compare instantiation; every older event of the window then qualifies.  Same rows as the walk."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    W = H = 64
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, 20000, 2, with_image=False, precomputed_feats=True))
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
+    nb.geom.delta_t_us = (1 << 24) + 5
+    outs = []
+    for variant in (3, 2):
+        nb.ell_variant = variant
+        outs.append(_ell_rows(nb, data, 2, dev))
+    assert float((outs[0][0] == 16).float().mean()) > 0.5
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_both_edge_search_kernels_give_the_same_rows():
     """Row scan (sparse windows), register-row spiral walk (dense windows) and wave-per-pixel search (dense input) on the
     same batch: identical ELL rows, degrees, pooled graph -- whichever the occupancy heuristic would pick."""
