@@ -345,6 +345,7 @@ class NativeBackbone:
         G0.x, G0.npos, G0.npix, G0.nbatch, G0.n_dev, G0.e_dev = hand.x, hand.npos, hand.npix, hand.nbatch, hand.n_dev, hand.e_dev
         G0.rowptr, G0.csr_src, G0.csr_dxy = hand.rowptr, hand.csr_src, hand.csr_dxy
         view = [G0] + levels[1:]
+        self._tail_view, self._tail_maps_used = view, tail_maps     # what graph_backward.PooledBackward walks back through
         if self._tail_arena_clean:
             self._tail_arena_clean = False                   # front() cleared it together with its own scratch
         else:

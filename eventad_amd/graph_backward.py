@@ -1,5 +1,6 @@
-"""Backward of the event-level stage through the native kernels (csrc/bwd.hip) -- LUT spline convolution, pool1's voxel
-max and the CNN-feature sampler: the gradients a fine-tuning of the DAGR backbone needs.  The reference gets it from autograd over MySplineConv's gather +
+"""Backward of the DAGR backbone through the native kernels: the event-level stage (csrc/bwd.hip -- LUT spline convolution,
+pool1's voxel max, the CNN-feature sampler) and the pooled levels (csrc/bwd_pooled.hip -- Layers 2..5, pools 2..4, samplers at
+pooled nodes): the gradients a fine-tuning of the backbone needs.  The reference gets it from autograd over MySplineConv's gather +
 scatter-add (src/dagr/model/layers/spline_conv.py:39-78); EventAD itself freezes the backbone (models/EventAD.py:148-150),
 so nothing here runs in its training step.
 
@@ -98,3 +99,117 @@ class EventPoolBackward:
         call("eventad_sample_bwd", grad_rows.data_ptr() + 4 * column, grad_rows.shape[1], channels, ptr(ws["posn_s"]),
              ptr(ws["pix_start"]), N, B, g.W, g.H, map_h, map_w, ptr(dmap), torch.cuda.current_stream().cuda_stream)
         return dmap
+
+
+class PooledBackward:
+    """Backward of NativeBackbone.tail(): Layers 2..5 on the pooled graphs (conv.py:59-72 over MySplineConv,
+    spline_conv.py:39-78), pools 2..4 (pooling.py:51-97) and the CNN-feature samplers at pooled nodes (net.py:200-228),
+    on the workspace the forward pass left behind.  The reference obtains these gradients from autograd.
+
+    Host logic only (csrc/bwd_pooled.hip + the GEMM of csrc/gemm.hip do the work): the node and edge counts of the levels
+    are read back once (a synchronisation -- this is a fine-tuning path, not part of EventAD's captured training step).
+    Gradients are not taken with respect to node positions (they do not depend on any parameter) nor with respect to the
+    BatchNorm statistics (eval mode)."""
+
+    def __init__(self, backbone):
+        load()
+        self.nb = backbone
+
+    def _levels(self):
+        view = getattr(self.nb, "_tail_view", None)
+        if view is None:
+            raise RuntimeError("PooledBackward: run NativeBackbone.tail() (or forward()) first")
+        return view
+
+    def counts(self):
+        """-> ([nodes per level], [edges per level]) of the last forward pass."""
+        view = self._levels()
+        nd = torch.cat([L.n_dev[:1] for L in view] + [L.e_dev[:1] for L in view]).cpu().tolist()
+        return nd[:4], nd[4:]
+
+    def transpose(self, lv, n, E):
+        """Out-edge lists of level lv's graph -> (out_start, out_edge, edge_dst)."""
+        L, dev = self._levels()[lv], self.nb.device
+        i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)
+        out_start, out_edge, edge_dst = i32(n + 1), i32(E), i32(E)
+        cnt, scan_tmp, tmp = i32(n + 1), i32(n // 2048 + 4), i32(E)     # named: each stays allocated until the call is issued
+        call("eventad_csr_transpose", ptr(L.rowptr), ptr(L.csr_src), n, E, ptr(out_start), ptr(out_edge), ptr(edge_dst),
+             ptr(cnt), ptr(scan_tmp), ptr(tmp), torch.cuda.current_stream().cuda_stream)
+        return out_start, out_edge, edge_dst
+
+    def layer(self, lv, n, E, g_y):
+        """Backward of Layer lv+2 on level lv.  g_y f32[n,64] = dL/d(layer output).
+        -> (dX f32[n, cin_pad] = dL/d(layer input rows [features | pos_x | pos_y | 0..]), {state_dict key: gradient})."""
+        nb, st = self.nb, torch.cuda.current_stream().cuda_stream
+        L, t, dev = self._levels()[lv], nb.tail_w[lv], nb.device
+        dvx, dvy = nb.geom.lut_div[lv + 1]
+        cin, cin_pad = t["cin"], t["cin_pad"]
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        g_y = g_y.contiguous().float()
+        assert tuple(g_y.shape) == (n, 64) and L.ldx == cin_pad
+        out_start, out_edge, edge_dst = self.transpose(lv, n, E)
+        # block 2: y = ReLU(bn2(blend(Z2) + Z2[root]) + bns(Z1[skip]))
+        d2, ds = f32(max(n, 1), 64), f32(max(n, 1), 64)
+        call("eventad_relu_scale_bwd", ptr(g_y), 64, ptr(L.y), 64, ptr(t["bn2"][0]), ptr(t["bns"][0]), n, 64, ptr(d2), ptr(ds), st)
+        dZ2 = f32(max(n, 1), 26 * 64)
+        call("eventad_tail_blend_bwd", ptr(d2), 64, ptr(out_start), ptr(out_edge), ptr(edge_dst), ptr(L.csr_dxy), n, dvx, dvy,
+             ptr(dZ2), 26 * 64, 25, None, 0, st)
+        dy1, dW2 = f32(max(n, 1), 64), torch.zeros(64, 26 * 64, device=dev)
+        call("eventad_gemm_f32_ex", 0, 1, ptr(dZ2), 26 * 64, ptr(t["wc2"]), 26 * 64, ptr(dy1), 64, n, 64, 26 * 64, None, 0, 0, st)
+        call("eventad_gemm_f32_ex", 1, 0, ptr(L.y1), 64, ptr(dZ2), 26 * 64, ptr(dW2), 26 * 64, 64, 26 * 64, n, None, 0, 0, st)
+        # block 1: y1 = ReLU(bn1(blend(Z1) + Z1[root]))
+        d1 = f32(max(n, 1), 64)
+        call("eventad_relu_scale_bwd", ptr(dy1), 64, ptr(L.y1), 64, ptr(t["bn1"][0]), None, n, 64, ptr(d1), None, st)
+        dZ1 = f32(max(n, 1), 27 * 64)
+        call("eventad_tail_blend_bwd", ptr(d1), 64, ptr(out_start), ptr(out_edge), ptr(edge_dst), ptr(L.csr_dxy), n, dvx, dvy,
+             ptr(dZ1), 27 * 64, 25, ptr(ds), 26, st)
+        dX, dW1 = f32(max(n, 1), cin_pad), torch.zeros(cin_pad, 27 * 64, device=dev)
+        call("eventad_gemm_f32_ex", 0, 1, ptr(dZ1), 27 * 64, ptr(t["wc1"]), 27 * 64, ptr(dX), cin_pad, n, cin_pad, 27 * 64, None, 0, 0, st)
+        call("eventad_gemm_f32_ex", 1, 0, L.x.data_ptr(), L.ldx, ptr(dZ1), 27 * 64, ptr(dW1), 27 * 64, cin_pad, 27 * 64, n, None, 0, 0, st)
+        from .weights import LAYER_NAMES
+        q1 = "%s%s.conv_block1." % (nb.prefix, LAYER_NAMES[lv + 1])
+        q2 = "%s%s.conv_block2." % (nb.prefix, LAYER_NAMES[lv + 1])
+        grads = {                                            # columns of [W_0..W_24 | root | skip] back to the reference's tensors
+            q1 + "conv.weight": dW1[:cin, :1600].reshape(cin, 25, 64).permute(1, 0, 2).contiguous(),
+            q1 + "conv.lin.weight": dW1[:cin, 1600:1664].t().contiguous(),
+            q2 + "lin.mlp.weight": dW1[:cin, 1664:1728].t().contiguous(),
+            q2 + "conv.weight": dW2[:, :1600].reshape(64, 25, 64).permute(1, 0, 2).contiguous(),
+            q2 + "conv.lin.weight": dW2[:, 1600:1664].t().contiguous(),
+        }
+        return dX[:n], grads
+
+    def pool(self, lv, n_in, n_out, dX):
+        """Backward of the pooling INTO level lv (lv = 1..3) and of the sampler that precedes it.  dX f32[n_out, cin_pad] =
+        dL/d(level lv's input rows).  -> (dy f32[n_in,64] = dL/d(output of the Layer on level lv-1), dmap f32[B,h,w,64])."""
+        nb, g, st = self.nb, self.nb.geom, torch.cuda.current_stream().cuda_stream
+        view = self._levels()
+        L, Lp, dev, B = view[lv], view[lv - 1], nb.device, nb._B
+        fmap = nb._tail_maps_used[lv - 1]
+        mean = 1 if g.pool_aggr[lv] == "mean" else 0
+        dX = dX.contiguous()
+        dy = torch.empty((max(n_in, 1), 64), device=dev)
+        dsamp = torch.empty((max(n_in, 1), 64), device=dev)
+        argm = torch.empty(max(n_out, 1) * 128, dtype=torch.int32, device=dev)
+        call("eventad_pool_max_bwd", ptr(Lp.y), 64, 64, ptr(fmap), fmap.shape[1], fmap.shape[2], 64, ptr(Lp.npos), ptr(Lp.nbatch),
+             ptr(Lp.node_slot_in), ptr(L.slot2node), ptr(L.cnt), n_in, n_out, g.W, g.H, mean, ptr(L.x), L.ldx, ptr(dX),
+             int(dX.shape[1]), ptr(argm), ptr(dy), ptr(dsamp), st)
+        dmap = torch.empty((B, fmap.shape[1], fmap.shape[2], 64), device=dev)
+        call("eventad_sample_nodes_bwd", ptr(dsamp), 64, ptr(Lp.npos), ptr(Lp.nbatch), ptr(Lp.occ), Lp.nx, Lp.ny, B, g.W, g.H,
+             fmap.shape[1], fmap.shape[2], ptr(dmap), st)
+        return dy[:n_in], dmap
+
+    def backward(self, g_out3, g_out4):
+        """g_out3 / g_out4 f32[n,64] = dL/d(out3.x) / dL/d(out4.x) (either may be None), rows = the levels' valid nodes.
+        -> dict(dx0 = dL/d(level-0 features) f32[n0,80], dmaps = [dL/d map2, map3, map4] (NHWC), weights = {key: grad})."""
+        n, E = self.counts()
+        dev = self.nb.device
+        weights, dmaps = {}, [None, None, None]
+        g_y = torch.zeros((n[3], 64), device=dev) if g_out4 is None else g_out4
+        for lv in (3, 2, 1, 0):
+            dX, gw = self.layer(lv, n[lv], E[lv], g_y)
+            weights.update(gw)
+            if lv == 0:
+                return dict(dx0=dX[:, :80].contiguous(), dmaps=dmaps, weights=weights)
+            g_y, dmaps[lv - 1] = self.pool(lv, n[lv - 1], n[lv], dX)
+            if lv == 3 and g_out3 is not None:
+                g_y = g_y + g_out3

@@ -350,6 +350,43 @@ int eventad_pool_seg0_bwd(const float* y2, const float* map_nhwc, int map_h, int
 int eventad_sample_bwd(const float* g, int ldg, int C, const float* posn_s, const uint32_t* pix_start, int N, int B,
                        int W, int H, int map_h, int map_w, float* dmap, void* stream);
 
+/* ---- (I') backward of the pooled levels: Layers 2..5 (conv.py:59-72 over MySplineConv, spline_conv.py:39-78), pools
+ * 2..4 (pooling.py:51-97) and the samplers at pooled nodes (net.py:200-228).  The reference obtains all of it from
+ * autograd.  With Z = X.[W_0..W_24 | root (| skip)] the forward is y = ReLU(scale * (blend(Z) + Z[root]) + shift (+ sscale *
+ * Z[skip] + sshift)); its backward is eventad_relu_scale_bwd, eventad_tail_blend_bwd over the transposed graph, and two
+ * eventad_gemm_f32_ex products (dX = dZ.W^T, dW = X^T.dZ).  No float atomics: bitwise reproducible. */
+/* Out-edges per source of a pooled graph in CSR form (rowptr u32[n+1], csr_src i32[E], rows = destinations).  out_start
+ * u32[n+1], out_edge i32[E] (edge ids, ascending inside a source's list), edge_dst i32[E] (destination of every edge).
+ * Scratch: cnt u32[n+1], scan_tmp u32[n/2048+2], tmp i32[E]. */
+int eventad_csr_transpose(const uint32_t* rowptr, const int32_t* csr_src, int n, int E, uint32_t* out_start,
+                          int32_t* out_edge, int32_t* edge_dst, uint32_t* cnt, uint32_t* scan_tmp, int32_t* tmp,
+                          void* stream);
+/* out_a[i,c] = g[i,c] * [y[i,c] > 0] * scale_a[c] (and out_b with scale_b when out_b != NULL): through the ReLU and the
+ * folded eval-mode BatchNorm scale(s).  out_a / out_b f32[n,C] dense. */
+int eventad_relu_scale_bwd(const float* g, int ldg, const float* y, int ldy, const float* scale_a, const float* scale_b,
+                           int n, int C, float* out_a, float* out_b, void* stream);
+/* dZ f32[n, ldz]: columns [0, 25*64) = gradient of the 25 kernel-cell products of every SOURCE node (gather over its
+ * out-edges, 4 bilinear taps each, same basis as eventad_tail_blend), block root_col = d (the root term), block skip_col
+ * = dskip (f32[n,64], nullable).  d f32[n, ldd] = gradient of the pre-BatchNorm convolution output (64 channels). */
+int eventad_tail_blend_bwd(const float* d, int ldd, const uint32_t* out_start, const int32_t* out_edge,
+                           const int32_t* edge_dst, const int32_t* csr_dxy, int n, float div_x, float div_y, float* dZ,
+                           int ldz, int root_col, const float* dskip, int skip_col, void* stream);
+/* Backward of eventad_pool_scatter (+ finalize) on a pooled level: the gradient of (output node, channel) goes to the
+ * member that attains the maximum (smallest member index among exactly equal ones: torch_scatter's CPU scatter_max), or
+ * to every member divided by the member count (mean != 0).  Inputs as the forward (xa = Ca layer-output channels of the
+ * n_in input nodes, Cm channels sampled from map_nhwc at the nodes' positions), node_slot i32[n_in] / slot2node i32[S] /
+ * cnt u32[S] as the forward left them, xout f32[n_out, ldo] = the pooled features, dxout f32[n_out, ldd] their gradient.
+ * Out: dxa f32[n_in, Ca], dsamp f32[n_in, Cm].  Scratch: argm i32[n_out * (Ca + Cm)]. */
+int eventad_pool_max_bwd(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
+                         const float* npos, const int32_t* nbatch, const int32_t* node_slot, const int32_t* slot2node,
+                         const uint32_t* cnt, int n_in, int n_out, int W, int H, int mean, const float* xout, int ldo,
+                         const float* dxout, int ldd, int32_t* argm, float* dxa, float* dsamp, void* stream);
+/* Transpose of the bilinear sampler at pooled nodes: dmap f32[B, map_h, map_w, C] (NHWC) from dsamp f32[n, C].  npos /
+ * nbatch = the nodes' positions and clips, occ u32[S+1] = the exclusive occupancy scan of the level's slot table (nodes
+ * are numbered in slot order), nx, ny = its voxel grid.  Gather per map pixel, fixed summation order. */
+int eventad_sample_nodes_bwd(const float* dsamp, int C, const float* npos, const int32_t* nbatch, const uint32_t* occ,
+                             int nx, int ny, int B, int W, int H, int map_h, int map_w, float* dmap, void* stream);
+
 /* ---- (J) streams restricted to a CU set (no counterpart in the reference) ------------------------------------------ */
 /* A default-priority HIP stream whose kernels may only use the CUs whose bit is set in mask (u32[words], bit i = CU i).
  * TrainStep uses a pair of them with disjoint masks for the backbone graph and the head graph. */
