@@ -270,6 +270,7 @@ class NativeBackbone:
         assert all(m.is_contiguous() for m in maps)
         # maps 2..4 feed the pooled stage: tail() on this pass's hand-off set reads them where they are
         self._tail_maps = maps[2:] if in_place else None
+        self._front_maps, self._N = maps[:2], N             # graph_backward.BackboneBackward reads them
         if not in_place:
             for i in range(2, 5):                            # mixed input: make the hand-off set complete
                 if maps[i].data_ptr() != hand.maps[i - 2].data_ptr():

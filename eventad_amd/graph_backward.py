@@ -213,3 +213,60 @@ class PooledBackward:
             g_y, dmaps[lv - 1] = self.pool(lv, n[lv - 1], n[lv], dX)
             if lv == 3 and g_out3 is not None:
                 g_y = g_y + g_out3
+
+
+class BackboneBackward:
+    """Backward of the whole graph branch (Net.forward, net.py:106-197) on the workspace of the last NativeBackbone.forward():
+    from dL/d(out3.x), dL/d(out4.x) to the gradients of the 25 weight tensors of the five Layers and of the five CNN feature
+    maps (NHWC; a trainable CNN branch continues from there with its own autograd).  PooledBackward for the pooled levels;
+    for the event level the glue around EventConvBackward / EventPoolBackward: ReLU and folded BatchNorm scales, the skip
+    projection of conv_block2 (conv.py:47-56) as two small GEMMs."""
+
+    def __init__(self, backbone, state_dict):
+        load()
+        nb = self.nb = backbone
+        pre = nb.prefix
+        self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if k.startswith(pre + "conv_block1.")}
+        self.pooled, self.conv, self.pool1 = PooledBackward(nb), EventConvBackward(nb.geom, nb.device), EventPoolBackward(nb)
+        p1, p2 = pre + "conv_block1.conv_block1.", pre + "conv_block1.conv_block2."
+        self.p1, self.p2 = p1, p2
+        dev = nb.device
+        self.sc1 = spline.fold_bn(self.sd, p1 + "norm.module.")[0].contiguous().to(dev)
+        self.sc2 = spline.fold_bn(self.sd, p2 + "norm.module.")[0].contiguous().to(dev)
+        self.scs = spline.fold_bn(self.sd, p2 + "norm_skip.module.")[0].contiguous().to(dev)
+        self.wskip = spline.pad_rows(self.sd[p2 + "lin.mlp.weight"].t().contiguous(), 20).t().contiguous().to(dev)   # [16, 20]
+
+    def backward(self, g_out3, g_out4):
+        """-> dict(weights = {state_dict key: gradient} (25 tensors), dmaps = [dL/d map0 .. map4] (NHWC))."""
+        nb, st = self.nb, torch.cuda.current_stream().cuda_stream
+        ws, g, dev, sd = nb.ws, nb.geom, nb.device, self.sd
+        N, B = nb._N, nb._B
+        res = self.pooled.backward(g_out3, g_out4)
+        weights, dmaps = dict(res["weights"]), [None, None] + res["dmaps"]
+        map0, map1 = nb._front_maps
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        # pool1: gradient rows of the level-0 nodes back to their voxel slots, then to the member events
+        L0 = ws["levels"][0]
+        n0 = res["dx0"].shape[0]
+        dfeat = torch.zeros((L0.S, 80), device=dev)
+        dfeat[L0.node_slot[:n0].long()] = res["dx0"]
+        dy2, dsamp = self.pool1.pool1(N, B, dfeat, fmap=map1)
+        dmaps[1] = self.pool1.sampler(N, B, dsamp, 64, map1.shape[1], map1.shape[2])
+        # conv_block2: y2 = ReLU(bn2(conv2(y1)) + bns(x0 . Wskip^T))
+        d2, ds = f32(max(N, 1), 16), f32(max(N, 1), 16)
+        call("eventad_relu_scale_bwd", ptr(dy2), 16, ptr(ws["y2"]), 16, ptr(self.sc2), ptr(self.scs), N, 16, ptr(d2), ptr(ds), st)
+        self.conv.transpose(ws, N)
+        dy1, dw, dr = self.conv.backward(ws, N, ws["y1"][:N], d2[:N], sd[self.p2 + "conv.weight"], sd[self.p2 + "conv.lin.weight"])
+        weights[self.p2 + "conv.weight"], weights[self.p2 + "conv.lin.weight"] = dw.to(dev), dr.to(dev)
+        dx_skip, dwskip = f32(max(N, 1), 20), torch.zeros((16, 20), device=dev)
+        call("eventad_gemm_f32_ex", 0, 0, ptr(ds), 16, ptr(self.wskip), 20, ptr(dx_skip), 20, N, 20, 16, None, 0, 0, st)
+        call("eventad_gemm_f32_ex", 1, 0, ptr(ds), 16, ptr(ws["x0s"]), 20, ptr(dwskip), 20, 16, 20, N, None, 0, 0, st)
+        weights[self.p2 + "lin.mlp.weight"] = dwskip[:, :19].contiguous()
+        # conv_block1: y1 = ReLU(bn1(conv1(x0)))
+        d1 = f32(max(N, 1), 16)
+        call("eventad_relu_scale_bwd", ptr(dy1), 16, ptr(ws["y1"]), 16, ptr(self.sc1), None, N, 16, ptr(d1), None, st)
+        dx0, dw, dr = self.conv.backward(ws, N, ws["x0s"][:N], d1[:N], sd[self.p1 + "conv.weight"], sd[self.p1 + "conv.lin.weight"])
+        weights[self.p1 + "conv.weight"], weights[self.p1 + "conv.lin.weight"] = dw.to(dev), dr.to(dev)
+        dx0 = dx0 + dx_skip[:N]
+        dmaps[0] = self.pool1.sampler(N, B, dx0, 16, map0.shape[1], map0.shape[2], column=1)
+        return dict(weights=weights, dmaps=dmaps, dx_events=dx0)

@@ -110,3 +110,49 @@ def test_csr_transpose_lists_every_edge_once_in_order():
     assert torch.equal(src[edges], owner)
     assert bool(((edges[1:] > edges[:-1]) | (owner[1:] != owner[:-1])).all())
     assert torch.equal(edge_dst.cpu().long(), torch.repeat_interleave(torch.arange(n), deg))
+
+
+@pytest.mark.parametrize("W,H,n,B,span,seed", [(64, 64, 3000, 2, 50000, 15), (96, 64, 6000, 3, 20000, 17), (256, 256, 20000, 2, 50000, 16)])
+def test_whole_graph_branch_backward_matches_autograd(W, H, n, B, span, seed):
+    """out3 / out4 cotangents -> gradients of all 25 weight tensors of the five Layers and of the five CNN maps, against
+    autograd through the oracle's whole Net.forward (same mask precondition as above, here also for Layer 1)."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    from eventad_amd.graph_backward import BackboneBackward
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True, t_span_us=span))
+    sd = weights.random_graph_state()
+    cfg = dagr_ref.make_config(W, H, B)
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(sd, W, H, dev)
+    out = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    torch.cuda.synchronize()
+    assert nb.check_flags() & ~1 == 0
+    keys = [k for k in sd if k.endswith("conv.weight") or k.endswith("lin.weight") or k.endswith("mlp.weight")]
+    assert len(keys) == 25
+    sdg = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    maps = [m.clone().requires_grad_(True) for m in data.image_feats]
+    (o3, o4), stages = dagr_ref.backbone_forward(sdg, data, cfg, maps, return_all=True, mode="ondemand")
+    N = data.pos.shape[0]
+    sid = nb.ws["sid"][:N].cpu().long()
+    y2 = torch.empty(N, 16)
+    y2[sid] = nb.ws["y2"][:N].cpu()
+    assert torch.equal(y2 > 0, stages["layer1"].x.detach() > 0), "seed precondition: a ReLU mask of Layer 1 differs"
+    for lv in range(4):
+        ref = stages["layer%d" % (lv + 2)].x.detach()
+        assert torch.equal(nb._tail_view[lv].y[: ref.shape[0]].cpu() > 0, ref > 0), "seed precondition: a ReLU mask differs"
+    g = torch.Generator().manual_seed(seed)
+    G3, G4 = torch.randn(o3.x.shape, generator=g), torch.randn(o4.x.shape, generator=g)
+    ((o3.x * G3).sum() + (o4.x * G4).sum()).backward()
+    bw = BackboneBackward(nb, sd)
+    res = bw.backward(G3.to(dev), G4.to(dev))
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.cpu() - b).abs().max()) / max(1e-6, float(b.abs().max()))
+    for k in range(5):
+        assert rel(res["dmaps"][k], maps[k].grad.permute(0, 2, 3, 1)) < 5e-4, (k, rel(res["dmaps"][k], maps[k].grad.permute(0, 2, 3, 1)))
+    assert sorted(res["weights"]) == sorted(keys)
+    for k in keys:
+        assert res["weights"][k].shape == sd[k].shape, k
+        assert rel(res["weights"][k], sdg[k].grad) < 1e-3, (k, rel(res["weights"][k], sdg[k].grad))
+    res2 = bw.backward(G3.to(dev), G4.to(dev))
+    assert all(torch.equal(res["weights"][k], res2["weights"][k]) for k in keys)
+    assert all(torch.equal(a, b) for a, b in zip(res["dmaps"], res2["dmaps"]))
