@@ -218,34 +218,43 @@ extern "C" int eventad_pool_max_bwd(const float* xa, int lda, int Ca, const floa
 
 // ------------------------------------------------------------------------------------------------ sampler at pooled nodes
 // dmap[b, y, x, :] = sum over the nodes of clip b whose bilinear footprint contains pixel (x, y) of weight * dsamp[node, :].
-// One workgroup of C threads per map pixel.  Nodes are numbered in ascending voxel-slot order, so the nodes of slot plane p
-// are the range [occ[p * plane], occ[(p + 1) * plane]); a node of clip b lies in plane b or b + 1 (an event at
-// t == time_window is clustered into the next plane, pooling.py:51-58 over grid_cluster).  The range is walked in ascending
-// order: a fixed summation order.
-__global__ void k_sample_nodes_bwd(const float* __restrict__ dsamp, int C, const float* __restrict__ npos, const int* __restrict__ nbatch,
-                                   const unsigned* __restrict__ occ, int plane, int S, int W, int H, int map_h, int map_w,
-                                   float* __restrict__ dmap) {
-    const int pix = blockIdx.x, c = threadIdx.x;
+// One wave per map pixel.  Nodes are numbered in ascending voxel-slot order, so the nodes of slot plane p are the range
+// [occ[p * plane], occ[(p + 1) * plane]); a node of clip b lies in plane b or b + 1 (an event at t == time_window is
+// clustered into the next plane, pooling.py:51-58 over grid_cluster).  The 64 lanes test 64 nodes of the range at a time;
+// the hits (ballot) are then added in ascending node order, lane = channel: a fixed summation order.
+__global__ __launch_bounds__(64) void k_sample_nodes_bwd(const float* __restrict__ dsamp, int C, const float* __restrict__ npos,
+                                                         const int* __restrict__ nbatch, const unsigned* __restrict__ occ, int plane, int S,
+                                                         int W, int H, int map_h, int map_w, float* __restrict__ dmap) {
+    const int pix = blockIdx.x, lane = threadIdx.x;
     const int b = pix / (map_h * map_w), rem = pix % (map_h * map_w), py = rem / map_w, px = rem % map_w;
     const int m0 = (int)occ[min(b * plane, S)], m1 = (int)occ[min((b + 2) * plane, S)];
     float acc = 0.f;
-    for (int m = m0; m < m1; ++m) {
-        if (nbatch[m] != b) continue;                                        // workgroup-uniform
-        int x0, y0; float fx, fy;
-        evad_bilinear_setup(npos[3 * m], npos[3 * m + 1], (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
-        const int ddx = px - x0, ddy = py - y0;
-        if (ddx < 0 || ddx > 1 || ddy < 0 || ddy > 1) continue;
-        const float wgt = (ddx ? fx : 1.f - fx) * (ddy ? fy : 1.f - fy);
-        acc += wgt * dsamp[(size_t)m * C + c];
+    for (int base = m0; base < m1; base += 64) {
+        const int m = base + lane;
+        bool hit = false; float wgt = 0.f;
+        if (m < m1 && nbatch[m] == b) {
+            int x0, y0; float fx, fy;
+            evad_bilinear_setup(npos[3 * m], npos[3 * m + 1], (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+            const int ddx = px - x0, ddy = py - y0;
+            hit = ddx >= 0 && ddx <= 1 && ddy >= 0 && ddy <= 1;
+            wgt = (ddx ? fx : 1.f - fx) * (ddy ? fy : 1.f - fy);
+        }
+        unsigned long long hits = __ballot(hit);
+        while (hits) {
+            const int l = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const float w = __shfl(wgt, l, 64);
+            if (lane < C) acc += w * dsamp[(size_t)(base + l) * C + lane];
+        }
     }
-    dmap[(size_t)pix * C + c] = acc;
+    if (lane < C) dmap[(size_t)pix * C + lane] = acc;
 }
 
 extern "C" int eventad_sample_nodes_bwd(const float* dsamp, int C, const float* npos, const int32_t* nbatch, const uint32_t* occ,
                                         int nx, int ny, int B, int W, int H, int map_h, int map_w, float* dmap, void* stream) {
-    if (!dsamp || !npos || !nbatch || !occ || !dmap || B <= 0 || C <= 0 || C > 1024 || nx <= 0 || ny <= 0 || map_h <= 0 || map_w <= 0)
+    if (!dsamp || !npos || !nbatch || !occ || !dmap || B <= 0 || C <= 0 || C > 64 || nx <= 0 || ny <= 0 || map_h <= 0 || map_w <= 0)
         return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_sample_nodes_bwd, dim3((unsigned)(B * map_h * map_w)), dim3(C), 0, (hipStream_t)stream, dsamp, C, npos, nbatch,
+    hipLaunchKernelGGL(k_sample_nodes_bwd, dim3((unsigned)(B * map_h * map_w)), dim3(64), 0, (hipStream_t)stream, dsamp, C, npos, nbatch,
                        occ, nx * ny, nx * ny * (B + 1), W, H, map_h, map_w, dmap);
     return evad_last_error();
 }

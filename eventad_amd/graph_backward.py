@@ -101,6 +101,22 @@ class EventPoolBackward:
         return dmap
 
 
+def _wgrad_group(problems, device, stream):
+    """C = A^T . B for up to 8 (A f32[K, >=M] lda, B f32[K, >=N] ldb, C f32[M, N], M, N, K) in ONE launch of the tiled grouped
+    GEMM: K (= the node or event count) is cut into 256-deep slabs that run on different workgroups, and the slabs are
+    summed in slab order by a second small launch (eventad_gemm_group) -- the plain GEMM would walk K serially on the few
+    workgroups an [M, N] weight matrix gives it."""
+    import ctypes
+    desc = (ctypes.c_int64 * (16 * len(problems)))()
+    keep = []
+    for i, (A, lda, Bm, ldb, C, M, N, K) in enumerate(problems):
+        part = torch.empty(((K + 255) // 256) * M * N, dtype=torch.float32, device=device) if K > 256 else None
+        keep.append(part)
+        desc[16 * i: 16 * i + 16] = [A.data_ptr(), Bm.data_ptr(), part.data_ptr() if part is not None else 0, C.data_ptr(), 0,
+                                     lda, ldb, N, M, N, K, 1, 0, 0, 0, 0]
+    call("eventad_gemm_group", len(problems), ctypes.cast(desc, ctypes.c_void_p), stream)
+
+
 class PooledBackward:
     """Backward of NativeBackbone.tail(): Layers 2..5 on the pooled graphs (conv.py:59-72 over MySplineConv,
     spline_conv.py:39-78), pools 2..4 (pooling.py:51-97) and the CNN-feature samplers at pooled nodes (net.py:200-228),
@@ -156,7 +172,6 @@ class PooledBackward:
              ptr(dZ2), 26 * 64, 25, None, 0, st)
         dy1, dW2 = f32(max(n, 1), 64), torch.zeros(64, 26 * 64, device=dev)
         call("eventad_gemm_f32_ex", 0, 1, ptr(dZ2), 26 * 64, ptr(t["wc2"]), 26 * 64, ptr(dy1), 64, n, 64, 26 * 64, None, 0, 0, st)
-        call("eventad_gemm_f32_ex", 1, 0, ptr(L.y1), 64, ptr(dZ2), 26 * 64, ptr(dW2), 26 * 64, 64, 26 * 64, n, None, 0, 0, st)
         # block 1: y1 = ReLU(bn1(blend(Z1) + Z1[root]))
         d1 = f32(max(n, 1), 64)
         call("eventad_relu_scale_bwd", ptr(dy1), 64, ptr(L.y1), 64, ptr(t["bn1"][0]), None, n, 64, ptr(d1), None, st)
@@ -165,7 +180,8 @@ class PooledBackward:
              ptr(dZ1), 27 * 64, 25, ptr(ds), 26, st)
         dX, dW1 = f32(max(n, 1), cin_pad), torch.zeros(cin_pad, 27 * 64, device=dev)
         call("eventad_gemm_f32_ex", 0, 1, ptr(dZ1), 27 * 64, ptr(t["wc1"]), 27 * 64, ptr(dX), cin_pad, n, cin_pad, 27 * 64, None, 0, 0, st)
-        call("eventad_gemm_f32_ex", 1, 0, L.x.data_ptr(), L.ldx, ptr(dZ1), 27 * 64, ptr(dW1), 27 * 64, cin_pad, 27 * 64, n, None, 0, 0, st)
+        if n > 0:                                            # dW = X^T . dZ for both blocks
+            _wgrad_group([(L.y1, 64, dZ2, 26 * 64, dW2, 64, 26 * 64, n), (L.x, L.ldx, dZ1, 27 * 64, dW1, cin_pad, 27 * 64, n)], dev, st)
         from .weights import LAYER_NAMES
         q1 = "%s%s.conv_block1." % (nb.prefix, LAYER_NAMES[lv + 1])
         q2 = "%s%s.conv_block2." % (nb.prefix, LAYER_NAMES[lv + 1])
@@ -260,7 +276,8 @@ class BackboneBackward:
         weights[self.p2 + "conv.weight"], weights[self.p2 + "conv.lin.weight"] = dw.to(dev), dr.to(dev)
         dx_skip, dwskip = f32(max(N, 1), 20), torch.zeros((16, 20), device=dev)
         call("eventad_gemm_f32_ex", 0, 0, ptr(ds), 16, ptr(self.wskip), 20, ptr(dx_skip), 20, N, 20, 16, None, 0, 0, st)
-        call("eventad_gemm_f32_ex", 1, 0, ptr(ds), 16, ptr(ws["x0s"]), 20, ptr(dwskip), 20, 16, 20, N, None, 0, 0, st)
+        if N > 0:
+            _wgrad_group([(ds, 16, ws["x0s"], 20, dwskip, 16, 20, N)], dev, st)
         weights[self.p2 + "lin.mlp.weight"] = dwskip[:, :19].contiguous()
         # conv_block1: y1 = ReLU(bn1(conv1(x0)))
         d1 = f32(max(N, 1), 16)

@@ -383,7 +383,7 @@ int eventad_pool_max_bwd(const float* xa, int lda, int Ca, const float* map_nhwc
                          const float* dxout, int ldd, int32_t* argm, float* dxa, float* dsamp, void* stream);
 /* Transpose of the bilinear sampler at pooled nodes: dmap f32[B, map_h, map_w, C] (NHWC) from dsamp f32[n, C].  npos /
  * nbatch = the nodes' positions and clips, occ u32[S+1] = the exclusive occupancy scan of the level's slot table (nodes
- * are numbered in slot order), nx, ny = its voxel grid.  Gather per map pixel, fixed summation order. */
+ * are numbered in slot order), nx, ny = its voxel grid, C <= 64.  Gather per map pixel, fixed summation order. */
 int eventad_sample_nodes_bwd(const float* dsamp, int C, const float* npos, const int32_t* nbatch, const uint32_t* occ,
                              int nx, int ny, int B, int W, int H, int map_h, int map_w, float* dmap, void* stream);
 
