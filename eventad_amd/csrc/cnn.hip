@@ -20,8 +20,11 @@ struct ConvP {
     float* part; int ksplit, kchunk;       // split-K: slab z covers k in [z*kchunk, (z+1)*kchunk) and goes to part[z][M][N]
 };
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
+// C16: Cin % 16 == 0 (every convolution of the trunk but the stem).  A 16-deep K slab then lies inside ONE (kh, kw) tap, so
+// the tap and the first channel of the slab are wave-uniform and advance incrementally from slab to slab: the loader's
+// per-thread integer divisions (about 200 VALU instructions per slab against its 32 MFMAs) become a few scalar ones.
+template <int TM, int TN, bool C16>
+__global__ __launch_bounds__(256, TM * TN == 4 ? 4 : 1) void k_conv_f32(ConvP p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AL = BM * (CBK / 4) / 256, BL = BN * (CBK / 4) / 256;
     __shared__ float As[2][CBK][BM + 4];
@@ -49,7 +52,26 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
     }
     float4 ra[AL], rb[BL];
     const int kend_ = p.ksplit > 1 ? min(K, ((int)blockIdx.z + 1) * p.kchunk) : K;
+    int s_kh = 0, s_kw = 0, s_ci = 0;                         // C16: tap and first channel of the slab that fetch() loads next
+    if (C16) {
+        const int kb = p.ksplit > 1 ? (int)blockIdx.z * p.kchunk : 0;
+        const int kk = kb / p.Cin;
+        s_ci = kb % p.Cin; s_kh = kk / p.KW; s_kw = kk % p.KW;
+    }
     auto fetch = [&](int k0) {                                 // slab k0 -> registers (global latency hides under MFMAs)
+        if (C16) {                                             // slabs are fetched in ascending order, 16 apart
+#pragma unroll
+            for (int t = 0; t < AL; ++t) {
+                const int kq = ((tid + t * 256) & 3) * 4;
+                const int ih = a_ih[t] + s_kh, iw = a_iw[t] + s_kw;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_base[t] >= 0 && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
+                    v = *(const float4*)(p.in + ((size_t)(a_base[t] + ih * p.IW + iw)) * p.Cin + s_ci + kq);
+                ra[t] = v;
+            }
+            s_ci += CBK;
+            if (s_ci >= p.Cin) { s_ci = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
+        } else {
 #pragma unroll
         for (int t = 0; t < AL; ++t) {
             int f = tid + t * 256, kq = (f & 3) * 4, gk = k0 + kq;
@@ -62,11 +84,12 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
             }
             ra[t] = v;
         }
+        }
 #pragma unroll
         for (int t = 0; t < BL; ++t) {
             int f = tid + t * 256, kr = f / (BN / 4), nq = (f % (BN / 4)) * 4, gk = k0 + kr, gn = n0 + nq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < kend_ && gn < N) v = *(const float4*)(p.w + (size_t)gk * N + gn);  // Cout % 4 == 0
+            if ((C16 || gk < kend_) && gn < N) v = *(const float4*)(p.w + (size_t)gk * N + gn);  // Cout % 4 == 0
             rb[t] = v;
         }
     };
@@ -91,19 +114,29 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvP p) {
     for (int k0 = kbeg; k0 < kend; k0 += CBK) {
         const bool more = k0 + CBK < kend;
         if (more) fetch(k0 + CBK);
+        {   // the operands of k-step kk + 2 are requested from LDS before the MFMAs of step kk are issued
+            const int c = lane & 31, kh2 = lane >> 5;
+            float a[2][TM], b[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < CBK; kk += 2) {
-            int kr = kk + (lane >> 5), c = lane & 31;
-            float a[TM], b[TN];
+            for (int i = 0; i < TM; ++i) a[0][i] = As[cur][kh2][wm + 32 * i + c];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr][wm + 32 * i + c];
+            for (int j = 0; j < TN; ++j) b[0][j] = Bs[cur][kh2][wn + 32 * j + c];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr][wn + 32 * j + c];
+            for (int kk = 0; kk < CBK; kk += 2) {
+                const int q = (kk >> 1) & 1;
+                if (kk + 2 < CBK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) a[q ^ 1][i] = As[cur][kk + 2 + kh2][wm + 32 * i + c];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) b[q ^ 1][j] = Bs[cur][kk + 2 + kh2][wn + 32 * j + c];
+                }
+                __builtin_amdgcn_sched_barrier(0);           // keep the reads above the MFMAs (the scheduler sinks them to their use)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+            }
         }
         if (more) stage(cur ^ 1);
         __syncthreads();
@@ -173,8 +206,11 @@ extern "C" int eventad_conv2d_nhwc(const float* in, const float* w, float* out, 
         }
     }
     dim3 grid((Cout + bt - 1) / bt, (unsigned)((M + bt - 1) / bt), p.ksplit);
-    if (big) hipLaunchKernelGGL((k_conv_f32<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else     hipLaunchKernelGGL((k_conv_f32<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    const bool c16 = Cin % CBK == 0;                         // then K and every split-K chunk are multiples of the slab depth
+    if (big) { if (c16) hipLaunchKernelGGL((k_conv_f32<2, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+               else     hipLaunchKernelGGL((k_conv_f32<2, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p); }
+    else     { if (c16) hipLaunchKernelGGL((k_conv_f32<1, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+               else     hipLaunchKernelGGL((k_conv_f32<1, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, p); }
     if (p.ksplit > 1) hipLaunchKernelGGL(k_conv_reduce, dim3(evad_blocks(MN, 256)), dim3(256), 0, (hipStream_t)stream, p, MN);
     return evad_last_error();
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ float epilogue(float v, int gm, int gn, const GemmEpi
 // and written to the OTHER LDS buffer afterwards, so global latency hides under the 8 x TM x TN MFMAs of a
 // slab and there is one barrier per slab instead of two.
 template <int TM, int TN, bool AT, bool BT>
-__global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+__global__ __launch_bounds__(256, TM * TN == 4 ? 4 : 1) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
                                                   float* __restrict__ C, int ldc, int M, const int* __restrict__ m_dev,
                                                   int N, int K, GemmEpi epi) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -109,19 +109,29 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
     for (int k0 = 0; k0 < K; k0 += GBK) {
         const bool more = k0 + GBK < K;
         if (more) fetch(k0 + GBK);
+        {   // the operands of k-step kk + 2 are requested from LDS before the MFMAs of step kk are issued
+            const int c = lane & 31, kh2 = lane >> 5;
+            float a[2][TM], b[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < GBK; kk += 2) {
-            int kr = kk + (lane >> 5), c = lane & 31;
-            float a[TM], b[TN];
+            for (int i = 0; i < TM; ++i) a[0][i] = As[cur][kh2][wm + 32 * i + c];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr][wm + 32 * i + c];
+            for (int j = 0; j < TN; ++j) b[0][j] = Bs[cur][kh2][wn + 32 * j + c];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr][wn + 32 * j + c];
+            for (int kk = 0; kk < GBK; kk += 2) {
+                const int q = (kk >> 1) & 1;
+                if (kk + 2 < GBK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) a[q ^ 1][i] = As[cur][kk + 2 + kh2][wm + 32 * i + c];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) b[q ^ 1][j] = Bs[cur][kk + 2 + kh2][wn + 32 * j + c];
+                }
+                __builtin_amdgcn_sched_barrier(0);           // keep the reads above the MFMAs (the scheduler sinks them to their use)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+            }
         }
         if (more) stage(cur ^ 1);
         __syncthreads();

@@ -8,12 +8,13 @@ from eventad_amd import synthetic
 from eventad_amd.dagr.utils.buffers import format_data
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 W, H, n, B, live = synthetic.CONFIGS[cfg]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else B            # clips per backbone pass (default: the configuration's batch)
 dev = torch.device("cuda:0")
 graphs, keep = [], []
 for i in range(2):
     args, model, sd = bench.build_model(W, H, B, dev, live_cnn=live)
     model.train()
-    data = format_data(synthetic.make_config_batch(cfg, first_clip=8 * i).to(dev))
+    data = format_data(synthetic.make_config_batch(cfg, first_clip=B * i, batch_size=B).to(dev))
     with torch.no_grad():
         for _ in range(3):
             model.extract_features(data, frames=(1,))
@@ -40,4 +41,4 @@ def run(which, reps=40):
     torch.cuda.synchronize()
     return a.elapsed_time(b) / (reps * len(which))
 for _ in range(2):
-    print("one chain: %.3f ms per batch; two interleaved chains: %.3f ms per batch" % (run([0]), run([0, 1])))
+    print("%d clips per pass -- one chain: %.3f ms per pass; two interleaved chains: %.3f ms per pass" % (B, run([0]), run([0, 1])))
