@@ -286,7 +286,7 @@ class NativeBackbone:
         self._tail_arena_clean = True
         self._c("eventad_sort_events", ptr(pos), ptr(batch), ptr(polarity), ptr(maps[0]), maps[0].shape[1], maps[0].shape[2],
              N, B, g.W, g.H, g.T, ptr(ws["key"]), ptr(ws["tq"]), ptr(ws["bev"]), ptr(ws["pix_count"]), ptr(ws["pix_start"]),
-             ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["sid"]), ptr(ws["counters"]),
+             ptr(ws["scan_tmp"]), ptr(ws["sid_tmp"]), ptr(ws["ell_src"]), ptr(ws["sid"]), ptr(ws["counters"]),   # record scratch (32 B per event) = the first half of ell_src, which the edge search only writes afterwards
              ptr(ws["key_s"]), ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["posn_s"]), ptr(ws["x0s"]), g.voxel[0][0], g.voxel[0][1],
              g.grid[0][0], g.grid[0][1], ptr(self.vox_tabs[0]), ptr(self.vox_tabs[1]), ptr(ws["node_slot0"]),
              ptr(ws["node_vox0"]), ptr(ws["ovf_list"]), self._front_zero_words, st)   # also clears counters, histogram, pool1 bitmap, work counters

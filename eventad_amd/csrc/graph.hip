@@ -359,10 +359,25 @@ __global__ void k_scatter_events(const int* __restrict__ key, const unsigned* __
     sid_tmp[start[key[i]] + arrival[i]] = i;             // unordered inside the segment; k_gather_sorted ranks by id
 }
 
+// The same placement, but the event travels with its id: a 32-byte record {id, pixel key, t, polarity | x, y, t, 0} at the
+// (unordered) slot of its pixel segment.  k_gather_sorted then finds everything it needs about an event in ONE coalesced
+// 32-byte read instead of five scattered 4..12-byte reads by event id (each of which costs a whole 32..64-byte sector).
+__global__ void k_scatter_records(const int* __restrict__ key, const unsigned* __restrict__ start, const int* __restrict__ arrival,
+                                  const int* __restrict__ tq, const float* __restrict__ pos, const float* __restrict__ pol,
+                                  int4* __restrict__ rec, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int k = key[i];
+    int4* r = rec + 2 * (size_t)(start[k] + arrival[i]);
+    r[0] = make_int4(i, k, tq[i], __float_as_int(pol[i]));
+    r[1] = make_int4(__float_as_int(pos[3 * i]), __float_as_int(pos[3 * i + 1]), __float_as_int(pos[3 * i + 2]), 0);
+}
+
 // Sorted-order event records + the 19(+1)-channel layer-1 input row
 //   x0s[r] = [polarity, 16 bilinear samples of CNN map 0, pos_x, pos_y, 0]   (reference net.py:116,122-123)
 // The sampler restates F.grid_sample(align_corners=True, zeros padding) as called by
 // net.py:211-228; the batch coordinate is integral so the trilinear blend reduces to bilinear.
+template <bool REC>      // REC: sid_tmp holds k_scatter_records' 32-byte records instead of bare event ids
 __global__ void k_gather_sorted(const int* __restrict__ sid_tmp, const unsigned* __restrict__ start, int* __restrict__ sid,
                                 const int* __restrict__ key, const int* __restrict__ tq,
                                 const float* __restrict__ pos, const float* __restrict__ pol,
@@ -377,21 +392,27 @@ __global__ void k_gather_sorted(const int* __restrict__ sid_tmp, const unsigned*
     // Thread t owns the event the counting sort dropped at (unordered) slot t of its pixel segment; its final
     // position is segment start + its id rank inside the segment (FIFO order = ascending id).  Ranking here
     // replaces two ordering launches; a segment of length L costs L loads per thread (L = 1..3 typically).
-    int i = sid_tmp[t];
-    int k = key[i];
+    int i, k, tqi; float px, py, pt, poli;
+    if (REC) {
+        const int4 a = ((const int4*)sid_tmp)[2 * (size_t)t], b4 = ((const int4*)sid_tmp)[2 * (size_t)t + 1];
+        i = a.x; k = a.y; tqi = a.z; poli = __int_as_float(a.w);
+        px = __int_as_float(b4.x); py = __int_as_float(b4.y); pt = __int_as_float(b4.z);
+    } else {
+        i = sid_tmp[t]; k = key[i]; tqi = tq[i]; poli = pol[i];
+        px = pos[3 * i]; py = pos[3 * i + 1]; pt = pos[3 * i + 2];
+    }
     int r = t;
     {
         unsigned s0 = start[k], s1 = start[k + 1];
         if (s1 - s0 > 1) {
             unsigned rank = 0;
-            for (unsigned c = s0; c < s1; ++c) rank += (sid_tmp[c] < i);
+            for (unsigned c = s0; c < s1; ++c) rank += ((REC ? sid_tmp[8 * (size_t)c] : sid_tmp[c]) < i);
             r = (int)(s0 + rank);
         }
     }
     sid[r] = i;
-    key_s[r] = k; ts_s[r] = tq[i];
-    if (ev2) ev2[r] = make_int2(i, tq[i]);
-    float px = pos[3 * i], py = pos[3 * i + 1], pt = pos[3 * i + 2];
+    key_s[r] = k; ts_s[r] = tqi;
+    if (ev2) ev2[r] = make_int2(i, tqi);
     posn_s[3 * r] = px; posn_s[3 * r + 1] = py; posn_s[3 * r + 2] = pt;
     int b = k / (W * H);
     if (node_slot) {
@@ -428,7 +449,7 @@ __global__ void k_gather_sorted(const int* __restrict__ sid_tmp, const unsigned*
     add(vx0 && vy0, y0, x0, w00); add(vx1 && vy0, y0, x0 + 1, w01);
     add(vx0 && vy1, y0 + 1, x0, w10); add(vx1 && vy1, y0 + 1, x0 + 1, w11);
     float4* o = (float4*)(x0s + (size_t)r * 20);
-    o[0] = make_float4(pol[i], acc[0].x, acc[0].y, acc[0].z);
+    o[0] = make_float4(poli, acc[0].x, acc[0].y, acc[0].z);
     o[1] = make_float4(acc[0].w, acc[1].x, acc[1].y, acc[1].z);
     o[2] = make_float4(acc[1].w, acc[2].x, acc[2].y, acc[2].z);
     o[3] = make_float4(acc[2].w, acc[3].x, acc[3].y, acc[3].z);
@@ -439,7 +460,7 @@ static int sort_events_impl(const float* pos, const int64_t* batch, const float*
                             const float* map0_nhwc, int map_h, int map_w,
                             int N, int B, int W, int H, int T,
                             int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
-                            uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid,
+                            uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* rec /* nullable: i32[N,8] */, int32_t* sid,
                             uint32_t* counters /* [0]=flags [2]=ovf count [3]=longest segment */,
                             int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s,
                             float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
@@ -466,8 +487,17 @@ static int sort_events_impl(const float* pos, const int64_t* batch, const float*
     int rc = evad_exclusive_scan_max(pix_count, pix_start, scan_tmp, P, counters + 3, st);   // [3] = longest pixel segment
     if (rc) return rc;
     if (N == 0) return evad_last_error();
+    if (rec) {
+        if ((uintptr_t)rec & 15) return EVAD_ERR_ARG;
+        hipLaunchKernelGGL(k_scatter_records, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, sid, tq, pos, polarity,
+                           (int4*)rec, N);
+        hipLaunchKernelGGL(k_gather_sorted<true>, dim3(evad_blocks(N, 256)), dim3(256), 0, st, rec, pix_start, sid, key, tq, pos,
+                           polarity, map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, (int2*)ev2, posn_s, x0s, vsx, vsy, nx, ny,
+                           nx * ny * (B + 1), px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, counters);
+        return evad_last_error();
+    }
     hipLaunchKernelGGL(k_scatter_events, dim3(evad_blocks(N, 256)), dim3(256), 0, st, key, pix_start, sid, sid_tmp, N);
-    hipLaunchKernelGGL(k_gather_sorted, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid_tmp, pix_start, sid, key, tq, pos, polarity,
+    hipLaunchKernelGGL(k_gather_sorted<false>, dim3(evad_blocks(N, 256)), dim3(256), 0, st, sid_tmp, pix_start, sid, key, tq, pos, polarity,
                        map0_nhwc, map_h, map_w, N, W, H, key_s, ts_s, (int2*)ev2, posn_s, x0s, vsx, vsy, nx, ny, nx * ny * (B + 1),
                        px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, counters);
     return evad_last_error();
@@ -477,12 +507,12 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
                                    const float* map0_nhwc, int map_h, int map_w,
                                    int N, int B, int W, int H, int T,
                                    int32_t* key, int32_t* tq, int32_t* bev, uint32_t* pix_count, uint32_t* pix_start,
-                                   uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* sid, uint32_t* counters,
+                                   uint32_t* scan_tmp, int32_t* sid_tmp, int32_t* rec, int32_t* sid, uint32_t* counters,
                                    int32_t* key_s, int32_t* ts_s, int32_t* ev2, float* posn_s, float* x0s,
                                    float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx, const int32_t* py_to_cy,
                                    int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words, void* stream) {
     return sort_events_impl(pos, batch, polarity, map0_nhwc, map_h, map_w, N, B, W, H, T, key, tq, bev, pix_count, pix_start, scan_tmp,
-                            sid_tmp, sid, counters, key_s, ts_s, ev2, posn_s, x0s, vsx, vsy, nx, ny, px_to_cx, py_to_cy, node_slot,
+                            sid_tmp, rec, sid, counters, key_s, ts_s, ev2, posn_s, x0s, vsx, vsy, nx, ny, px_to_cx, py_to_cy, node_slot,
                             node_vox, ovf_list, zero_tail_words, stream);
 }
 
@@ -536,7 +566,8 @@ extern "C" int eventad_sort_events_static(const float* pos, const int64_t* batch
     if (rc) return rc;
     // the histogram is cleared by sort_events_impl (fill kernel) on every call: the array keeps the last call's contents
     return sort_events_impl(pos, batch, polarity, map0_nhwc, map_h, map_w, N, B, W, H, T, key, tq, bev, ws /* pix_count */, pix_start,
-                            ws + EVAD_STATIC_OFF_SCAN, (int32_t*)(ws + EVAD_STATIC_OFF_SID), sid, counters, key_s, ts_s, ev2, posn_s,
+                            ws + EVAD_STATIC_OFF_SCAN, (int32_t*)(ws + EVAD_STATIC_OFF_SID), nullptr /* no record scratch: ids only */, sid, counters,
+                            key_s, ts_s, ev2, posn_s,
                             x0s, vsx, vsy, nx, ny, px_to_cx, py_to_cy, node_slot, node_vox, ovf_list, 0, stream);
 }
 

@@ -63,7 +63,9 @@ int eventad_format_events(const int16_t* pos, const int32_t* t, const int8_t* x,
  *   in : pos f32[N,3] normalised, batch i64[N], polarity f32[N], map0 f32[B,h,w,16] (NHWC)
  *   out: key/tq/bev i32[N] (event order: pixel key, t in us, clip), pix_start u32[B*H*W+1],
  *        sid i32[N] (event id at sorted position), key_s/ts_s i32[N], ev2 i32[N,2] = {id, t} pairs (nullable), posn_s f32[N,3], x0s f32[N,20]
- *   ws : pix_count u32[B*H*W+1], scan_tmp u32[2*(B*H*W/2048+2)], sid_tmp i32[N],
+ *   ws : pix_count u32[B*H*W+1], scan_tmp u32[2*(B*H*W/2048+2)], sid_tmp i32[N], rec (nullable, 16-byte aligned)
+ *        i32[N,8]: with it every event is placed as a 32-byte record {id, key, t, polarity | x, y, t, 0} and the gather
+ *        pass reads records instead of chasing event ids (same results; sid_tmp is then unused),
  *        counters u32[4], zeroed by this call -- the first of a step ([0] = EVENTAD_FLAG_* bits, accumulated by the
  *        later stages; [1] unused; [2] = length of ovf_list; [3] = longest pixel segment of the batch).
  *        When pix_count == counters + 4 the two are cleared by ONE memset, which then also covers the
@@ -75,7 +77,7 @@ int eventad_format_events(const int16_t* pos, const int32_t* t, const int8_t* x,
 int eventad_sort_events(const float* pos, const int64_t* batch, const float* polarity, const float* map0_nhwc,
                         int map_h, int map_w, int N, int B, int W, int H, int T, int32_t* key, int32_t* tq,
                         int32_t* bev, uint32_t* pix_count, uint32_t* pix_start, uint32_t* scan_tmp, int32_t* sid_tmp,
-                        int32_t* sid, uint32_t* counters, int32_t* key_s, int32_t* ts_s, int32_t* ev2,
+                        int32_t* rec, int32_t* sid, uint32_t* counters, int32_t* key_s, int32_t* ts_s, int32_t* ev2,
                         float* posn_s, float* x0s, float vsx, float vsy, int nx, int ny, const int32_t* px_to_cx,
                         const int32_t* py_to_cy, int32_t* node_slot, int32_t* node_vox, int32_t* ovf_list, int zero_tail_words,
                         void* stream);

@@ -28,10 +28,10 @@ def _run(static, data, B, W, H, g, tabs, dev):
     else:
         pix_count = torch.full((P + 1,), 12345, dtype=torch.int32, device=dev)
         scan_tmp = i32(2 * (max(P, 1 << 16) // 2048 + 4))
-        sid_tmp = i32(N)
-        call("eventad_sort_events", ptr(pos), ptr(batch), ptr(pol), ptr(m0), m0.shape[1], m0.shape[2], N, B, W, H, g.T,
+        sid_tmp, rec = i32(N), i32(max(N, 1), 8)               # with `rec` the workspace form places 32-byte records, the
+        call("eventad_sort_events", ptr(pos), ptr(batch), ptr(pol), ptr(m0), m0.shape[1], m0.shape[2], N, B, W, H, g.T,   # static form bare ids
              ptr(o["key"]), ptr(o["tq"]), ptr(o["bev"]), ptr(pix_count), ptr(o["pix_start"]), ptr(scan_tmp), ptr(sid_tmp),
-             ptr(o["sid"]), ptr(o["counters"]), *common_out, 0, st)
+             ptr(rec), ptr(o["sid"]), ptr(o["counters"]), *common_out, 0, st)
     torch.cuda.synchronize()
     n_ovf = int(o["counters"][2].item())
     o["ovf_list"] = torch.sort(o["ovf_list"][:n_ovf]).values          # appended with an atomic counter: a set, not a sequence
