@@ -130,67 +130,150 @@ extern "C" int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_star
 }
 
 // ------------------------------------------------------------------------------------------------ dL/dLUT
-// Stage 1: workgroup w walks destinations [w*chunk, (w+1)*chunk) in order; thread t = (k, o) owns element (k, o) of every
-// matrix: acc[cell][t] lives in LDS, touched by that thread only.  Rows x_src and g_dst of 16 edges at a time are staged
-// in LDS by the workgroup.  Stage 2: partial tables summed in workgroup order.
-#define BW_EDGES 32
+// dLUT[c] = sum over the edges with spiral step c of x_src (x) g_dst: per step an [edges_c x Cin]^T . [edges_c x 16] product.
+// A workgroup takes 256 consecutive destinations (thread t = destination t of the chunk, its ELL row = 16 slots):
+//  (1) stable counting sort of the chunk's valid slots by step, in LDS: per-thread counts per step, a prefix over the
+//      threads per step (so the order inside a step is ascending slot id: a fixed summation order), placement;
+//  (2) the 4 waves take the steps round-robin; a step's edges go through fp32 MFMA 16x16x4 four at a time -- lane l holds
+//      channel l & 15 of the source row and output l & 15 of the gradient row of edge l >> 4, straight from memory -- into one
+//      (Cin = 16) or two (Cin = 20: channels 16..19 in a second tile) accumulators, written once per step to the
+//      workgroup's partial table.
+// Stage 2 sums the partial tables in workgroup order.  (The previous form kept the accumulators in LDS and paid a
+// read-modify-write plus three operand reads per FMA: 1.85 ms per convolution at 400k events, against 0.1 ms of traffic.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define BW_CHUNK 256
 template <int CINP>
-__global__ __launch_bounds__(CINP * 16) void k_conv_bwd_weight(const float* __restrict__ x, const float* __restrict__ g,
-                                                               const int* __restrict__ ell_src, const uint16_t* __restrict__ ell_step,
-                                                               const int* __restrict__ deg, float* __restrict__ partial, int N,
-                                                               int steps, int chunk) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int T = CINP * 16;
-    float* s_acc = smem;                                   // [steps+1][T]
-    float* s_x = s_acc + (size_t)(steps + 1) * T;          // [BW_EDGES][CINP]
-    float* s_g = s_x + BW_EDGES * CINP;                    // [BW_EDGES][16]
-    int* s_cell = (int*)(s_g + BW_EDGES * 16);             // [BW_EDGES]
-    const int tid = threadIdx.x, k = tid >> 4, o = tid & 15;
-    for (int c = 0; c <= steps; ++c) s_acc[c * T + tid] = 0.f;
-    const int n0 = blockIdx.x * chunk, n1 = min(n0 + chunk, N);
-    // flat edge walk over the chunk's ELL slots, BW_EDGES slots per round (slots past a row's degree are skipped)
-    for (long long e0 = (long long)n0 * 16; e0 < (long long)n1 * 16; e0 += BW_EDGES) {
-        __syncthreads();
-        if (tid < BW_EDGES) {
-            const long long e = e0 + tid;
-            const int i = (int)(e >> 4), slot = (int)(e & 15);
-            int cell = -1;
-            if (i < n1 && slot < deg[i]) cell = slot == 0 ? steps : (int)ell_step[e];
-            s_cell[tid] = cell;
+__global__ __launch_bounds__(256) void k_conv_bwd_weight(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const int* __restrict__ ell_src, const uint16_t* __restrict__ ell_step,
+                                                         const int* __restrict__ deg, float* __restrict__ partial, int N, int steps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bins = steps + 1, T = CINP * 16;
+    unsigned short* s_hist = (unsigned short*)smem;                          // [bins][256]: counts, then exclusive prefixes over threads
+    unsigned short* s_sorted = s_hist + (size_t)bins * BW_CHUNK;            // [4096]: slot index inside the chunk, by step
+    int* s_src = (int*)(s_sorted + BW_CHUNK * 16);                          // [4096]: source node of the slot at that position
+    unsigned* s_start = (unsigned*)(s_src + BW_CHUNK * 16);                 // [bins + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BW_CHUNK, i = n0 + tid;
+    for (int c = 0; c < bins; ++c) s_hist[c * BW_CHUNK + tid] = 0;
+    const int d = i < N ? min(deg[i], 16) : 0;
+    unsigned short cells[16];
+    int srcs[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { cells[k] = 0; srcs[k] = 0; }
+    if (d > 0) {
+        const int4* srow = (const int4*)(ell_src + (size_t)i * 16);
+        const int4 q0 = srow[0], q1 = srow[1], q2 = srow[2], q3 = srow[3];
+        srcs[0] = q0.x; srcs[1] = q0.y; srcs[2] = q0.z; srcs[3] = q0.w; srcs[4] = q1.x; srcs[5] = q1.y; srcs[6] = q1.z; srcs[7] = q1.w;
+        srcs[8] = q2.x; srcs[9] = q2.y; srcs[10] = q2.z; srcs[11] = q2.w; srcs[12] = q3.x; srcs[13] = q3.y; srcs[14] = q3.z; srcs[15] = q3.w;
+        const uint4* row = (const uint4*)(ell_step + (size_t)i * 16);       // 16 x u16 = 32 bytes
+        const uint4 r0 = row[0], r1 = row[1];
+        const unsigned w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cells[k] = (unsigned short)(k == 0 ? steps : min((int)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), steps - 1));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < d) s_hist[cells[k] * BW_CHUNK + tid] += 1;      // private column: no atomics
+    }
+    __syncthreads();
+    // per step: exclusive prefix of the counts over the 256 threads (lane = 4 consecutive threads), step totals
+    for (int c = wave; c < bins; c += 4) {
+        unsigned short* h = s_hist + c * BW_CHUNK + 4 * lane;
+        const unsigned a0 = h[0], a1 = h[1], a2 = h[2], a3 = h[3], sum = a0 + a1 + a2 + a3;
+        unsigned inc = sum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const unsigned t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
+        const unsigned ex = inc - sum;
+        h[0] = (unsigned short)ex; h[1] = (unsigned short)(ex + a0); h[2] = (unsigned short)(ex + a0 + a1); h[3] = (unsigned short)(ex + a0 + a1 + a2);
+        if (lane == 63) s_start[c + 1] = inc;                               // total of the step (scanned below)
+    }
+    __syncthreads();
+    if (wave == 0) {                                                         // exclusive scan of the step totals
+        unsigned carry = 0;
+        for (int c0 = 0; c0 < bins; c0 += 64) {
+            const int c = c0 + lane;
+            const unsigned v = c < bins ? s_start[c + 1] : 0u;
+            unsigned inc = v;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const unsigned t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
+            if (c < bins) s_start[c + 1] = carry + inc;
+            carry += __shfl(inc, 63, 64);
         }
-        __syncthreads();
-        for (int t = tid; t < BW_EDGES * CINP; t += T) {
-            const int r = t / CINP, c = t - r * CINP;
-            if (s_cell[r] >= 0) s_x[t] = x[(size_t)ell_src[e0 + r] * CINP + c];
+        if (lane == 0) s_start[0] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < d) {
+            const int c = cells[k];
+            const unsigned p = s_start[c] + s_hist[c * BW_CHUNK + tid];
+            s_hist[c * BW_CHUNK + tid] += 1;
+            s_sorted[p] = (unsigned short)(tid * 16 + k);
+            s_src[p] = srcs[k];
         }
-        for (int t = tid; t < BW_EDGES * 16; t += T) {
-            const int r = t >> 4;
-            if (s_cell[r] >= 0) s_g[t] = g[(size_t)((e0 + r) >> 4) * 16 + (t & 15)];
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * bins * T;
+    const int j = lane >> 4, m = lane & 15;
+    for (int c = wave; c < bins; c += 4) {
+        const unsigned e0 = s_start[c], e1 = s_start[c + 1];
+        f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
+        for (unsigned e = e0; e < e1; e += 16) {                             // four MFMA steps (16 edges) per trip: their loads overlap
+            float a0[4], a1[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned idx = e + 4 * u + j;
+                const bool ok = idx < e1;
+                const int slot = ok ? (int)s_sorted[idx] : 0;
+                const int src = ok ? s_src[idx] : 0;
+                const int dst = n0 + (slot >> 4);
+                a0[u] = ok ? x[(size_t)src * CINP + m] : 0.f;
+                a1[u] = (CINP == 20 && ok && m < 4) ? x[(size_t)src * CINP + 16 + m] : 0.f;
+                b[u] = ok ? g[(size_t)dst * 16 + m] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b[u], D0, 0, 0, 0);
+                if (CINP == 20) D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b[u], D1, 0, 0, 0);
+            }
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < BW_EDGES; ++r) {
-            const int cell = s_cell[r];
-            if (cell >= 0) s_acc[cell * T + tid] = fmaf(s_x[r * CINP + k], s_g[r * 16 + o], s_acc[cell * T + tid]);
+        // D[4 * (lane >> 4) + r][lane & 15]: row = input channel, column = output
+        float* oc = out + (size_t)c * T;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oc[(4 * j + r) * 16 + m] = D0[r];
+        if (CINP == 20 && j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oc[(16 + r) * 16 + m] = D1[r];
         }
     }
-    float* out = partial + (size_t)blockIdx.x * (steps + 1) * T;
-    for (int c = 0; c <= steps; ++c) out[c * T + tid] = s_acc[c * T + tid];
 }
 
-__global__ void k_sum_partials(const float* __restrict__ partial, int n_part, int len, float* __restrict__ out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= len) return;
-    float s = 0.f;
-    for (int p = 0; p < n_part; ++p) s += partial[(size_t)p * len + t];
-    out[t] = s;
+// 16 elements x 16 groups per workgroup: group q adds the tables q, q + 16, ... (four independent running sums, combined in a
+// fixed order), the 16 group sums are then added in group order -- the same bits in every run.
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ partial, int n_part, int len, float* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, q = threadIdx.x >> 4, t = blockIdx.x * 16 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (t < len) {
+        int p = q;
+        for (; p + 48 < n_part; p += 64) {
+            s0 += partial[(size_t)p * len + t]; s1 += partial[(size_t)(p + 16) * len + t];
+            s2 += partial[(size_t)(p + 32) * len + t]; s3 += partial[(size_t)(p + 48) * len + t];
+        }
+        for (; p < n_part; p += 16) s0 += partial[(size_t)p * len + t];
+    }
+    red[q][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && t < len) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][el];
+        out[t] = s;
+    }
 }
 
 // x f32[N, Cin_pad] (the conv's input rows), g f32[N,16]; dlut f32[steps+1][Cin_pad][16] in NATURAL channel order;
 // partial = scratch f32[n_part][steps+1][Cin_pad][16] with n_part = eventad_l1_conv_bwd_weight_parts(N).
 extern "C" int eventad_l1_conv_bwd_weight_parts(int N) {
-    int parts = (N + 255) / 256;
-    return parts < 1 ? 1 : (parts > 1024 ? 1024 : parts);
+    const int parts = (N + BW_CHUNK - 1) / BW_CHUNK;
+    return parts < 1 ? 1 : parts;
 }
 
 extern "C" int eventad_l1_conv_bwd_weight(const float* x, const float* g, const int32_t* ell_src, const uint16_t* ell_step,
@@ -198,24 +281,23 @@ extern "C" int eventad_l1_conv_bwd_weight(const float* x, const float* g, const 
                                           void* stream) {
     if (!x || !g || !ell_src || !ell_step || !deg || !partial || !dlut || N < 0 || steps < 1 || (cin_pad != 20 && cin_pad != 16))
         return EVAD_ERR_ARG;
-    const int T = cin_pad * 16;
-    const size_t lds = sizeof(float) * ((size_t)(steps + 1) * T + BW_EDGES * (cin_pad + 16)) + sizeof(int) * BW_EDGES;
-    if (lds > 150 * 1024) return EVAD_ERR_ARG;             // larger search radii: not implemented for the backward pass
+    const int T = cin_pad * 16, bins = steps + 1;
+    const size_t lds = sizeof(unsigned short) * ((size_t)bins * BW_CHUNK + BW_CHUNK * 16) + sizeof(int) * BW_CHUNK * 16 + sizeof(unsigned) * (bins + 1);
+    if (lds > 150 * 1024) return EVAD_ERR_ARG;             // search radii above 7 px: not implemented for the backward pass
     hipStream_t st = (hipStream_t)stream;
     const int parts = eventad_l1_conv_bwd_weight_parts(N);
-    const int chunk = (N + parts - 1) / parts > 0 ? (N + parts - 1) / parts : 1;
     static size_t attr[2] = {0, 0};
     if (cin_pad == 20) {
         auto kern = k_conv_bwd_weight<20>;
         if (attr[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
-        hipLaunchKernelGGL(kern, dim3(parts), dim3(T), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, chunk);
+        hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps);
     } else {
         auto kern = k_conv_bwd_weight<16>;
         if (attr[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
-        hipLaunchKernelGGL(kern, dim3(parts), dim3(T), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, chunk);
+        hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps);
     }
-    const int len = (steps + 1) * T;
-    hipLaunchKernelGGL(k_sum_partials, dim3(evad_blocks(len, 256)), dim3(256), 0, st, partial, parts, len, dlut);
+    const int len = bins * T;
+    hipLaunchKernelGGL(k_sum_partials, dim3(evad_blocks(len, 16)), dim3(256), 0, st, partial, parts, len, dlut);
     return evad_last_error();
 }
 

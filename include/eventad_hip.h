@@ -332,7 +332,8 @@ int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_start, const in
                              const float* lut, float* dx, int N, int steps, int cin_pad, void* stream);
 /* dlut[c] = sum over edges with spiral step c of x_src (x) g_dst, f32[steps+1][cin_pad][16] in natural channel order (row
  * `steps` = the self edges: gradient of LUT[0] + W_root).  partial = scratch f32[eventad_l1_conv_bwd_weight_parts(N)]
- * [steps+1][cin_pad][16]. */
+ * [steps+1][cin_pad][16] (one table per 256 destinations).  (steps+1) * 512 bytes + 24 KB must fit in LDS (search radius
+ * <= 7 px), else -1. */
 int eventad_l1_conv_bwd_weight_parts(int N);
 int eventad_l1_conv_bwd_weight(const float* x, const float* g, const int32_t* ell_src, const uint16_t* ell_step,
                                const int32_t* deg, float* partial, float* dlut, int N, int steps, int cin_pad, void* stream);
