@@ -890,9 +890,6 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
                                              int* my_src, unsigned short* my_stp, const int2* my_dest, int* my_cnt) {
     constexpr int MAXNB = 16, NG = 64 / GS;
     const int lane = threadIdx.x & 63, g = lane / GS, l = lane % GS;
-    const int gshift = g * GS;
-    const unsigned long long gmask = GS == 64 ? ~0ull : ((1ull << GS) - 1ull);
-    const unsigned long long below = (1ull << l) - 1ull;
     const float fdt = (float)dt_max;
     const int i = i0 + l;
     const int ii = min(i, steps - 1);
@@ -907,7 +904,7 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
     for (int v = 0; v < PIX_DEPTH; ++v) {
         const int2 c = ev2[min(max(en - 1 - v, lo), N - 1)];
         eid[v] = v < lenr ? c.x : 0x7fffffff;                // padding counts as "not older" and is subtracted again (ninv)
-        et[v] = c.y;
+        et[v] = v < lenr ? c.y : -(1 << 30);                 // ... and as out of the time window
     }
     // oldest entry of a deep pixel: if even that one is not older than the event, nothing below the registers is
     const int eold = len > PIX_DEPTH ? ev2[min(lo, N - 1)].x : 0x7fffffff;
@@ -927,17 +924,20 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
         const int base = my_cnt[d];
         const int2 mine = my_dest[d];
         const int me = mine.x, ts = mine.y;
-        int cge = 0, nq = 0;
+        // Entries run from the newest to older ones, so "not older than the event" holds for a prefix of them and "inside the
+        // time window" for a prefix too (timestamps ascend with the ids here): two independent counts, and the sources are
+        // the entries between the two prefixes.
+        int cge = 0, nin = 0;
 #pragma unroll
         for (int v = 0; v < PIX_DEPTH; ++v) {
-            const bool older = eid[v] < me;
             const int dt = ts - et[v];
             // (float)(ts - t) > (float)delta_t  <=>  ts - t > delta_t  whenever |delta_t| + 1 is exactly representable
             const bool far = INT_CMP ? dt > dt_max : (float)dt > fdt;
-            cge += older ? 0 : 1;
-            nq += (older && !far) ? 1 : 0;
+            cge += eid[v] < me ? 0 : 1;
+            nin += far ? 0 : 1;
         }
         int nnew = cge - ninv;
+        int nq = max(0, nin - nnew);
         if (!act) nq = 0;
         if (act && eold < me && nnew + nq == PIX_DEPTH) {                // deep pixel, registers undecided: read on
             for (int s = en - 1 - PIX_DEPTH; s >= lo && nq < MAXNB; --s) {
@@ -948,20 +948,22 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
                 ++nq;
             }
         }
-        // exclusive sum of nq over the lower lanes of the group and its total: one ballot per level of nq
-        int off = 0, tot = 0;
-        for (int k = 0; k < MAXNB; ++k) {
-            const unsigned long long m = __ballot(nq > k);
-            if (!m) break;
-            const unsigned long long mg = (m >> gshift) & gmask;
-            off += __popcll(mg & below); tot += __popcll(mg);
-        }
+        // inclusive sum of nq over the lanes of the group, lane order = spiral order: a shift-and-add scan inside each row of
+        // 16 lanes (DPP row_shr 1, 2, 4, 8), then the last lane of a row added to the whole next row where a group spans rows
+        int inc = nq;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+        if (GS >= 32) inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);    // row_bcast15 -> rows 1 and 3
+        if (GS == 64) inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);    // row_bcast31 -> rows 2 and 3
+        const int off = inc - nq;
         const int take = min(nq, MAXNB - base - off);        // slots left for this lane's sources
         for (int k = 0; k < take; ++k) {
             my_src[d * MAXNB + base + off + k] = en - 1 - nnew - k;
             my_stp[d * MAXNB + base + off + k] = (unsigned short)i;
         }
-        if (l == 0 && act) my_cnt[d] = min(MAXNB, base + tot);
+        if (l == GS - 1 && act) my_cnt[d] = min(MAXNB, base + inc);      // the group's last lane holds the total
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS written by one lane, read by others of the wave
 }
