@@ -63,9 +63,9 @@ class HookModule(nn.Module):
         self.feature_channels = list(feature_channels)
         self.register_load_state_dict_post_hook(HookModule._drop_native)
 
-    def train(self, mode=True):
-        self._native = None
-        return super().train(mode)
+    # (train()/eval() do not touch the native weight images: the trunk always runs with eval-mode BatchNorm folded into
+    # its convolutions, and EventADModel.extract_features calls dagr_model.eval() on every step -- dropping the images
+    # there meant 58 strided weight copies, 100 MB, per forward pass)
 
     def _apply(self, fn, *a, **k):                      # .to()/.cuda(): weights move -> rebuild the native images
         self._native = None

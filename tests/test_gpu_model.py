@@ -108,6 +108,19 @@ def test_live_cnn_branch_matches_oracle():
     got = torch.cat([o for frame in outputs for o in frame], 0).cpu()
     want = torch.cat([o[2] for o in outs], 0).detach()
     assert float((got - want).abs().max()) < 1e-3 and torch.equal(got.argmax(1), want.argmax(1))
+    # the trunk's native weight images are built once: eval()/train() (extract_features calls eval() on every step) keep
+    # them, a state-dict load or a device move drops them
+    hook = model.dagr_model.backbone.net
+    native = hook._native
+    assert native is not None
+    model.train(); model.eval()
+    with torch.no_grad():
+        model(data, data.bbox[:, 4])
+    assert hook._native is native
+    model.load_state_dict(model.state_dict())
+    assert hook._native is None
+    got2 = hook(data.image)
+    assert all(torch.equal(a, b) for a, b in zip(got2, model.dagr_model.backbone.net(data.image)))
 
 
 @pytest.mark.parametrize("W,H,B,n", [(64, 64, 1, 5000),          # the single-clip configuration: B = 1 takes the sampler's B' = max(B, 2) branch
