@@ -325,9 +325,9 @@ __global__ __launch_bounds__(256) void k_loss_sum(const float* __restrict__ loss
 extern "C" int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const float* bo, const int32_t* target,
                                 const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss,
                                 float* dPre, void* stream) {
-    if (!F1r || !Wo || !bo || !target || !valid || !logits || !dlog || !loss_rows || !loss || R <= 0) return EVAD_ERR_ARG;
+    if (!F1r || !Wo || !bo || !target || !valid || !logits || !dlog || !loss_rows || R <= 0) return EVAD_ERR_ARG;
     hipLaunchKernelGGL(k_fuse_out, dim3(R), dim3(64), 0, (hipStream_t)stream, F1r, D2, Wo, bo, target, valid, R, logits, dlog, loss_rows, dPre);
-    hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, R, loss);
+    if (loss) hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, R, loss);   // else: eventad_out_bwd adds the rows
     return evad_last_error();
 }
 
@@ -345,8 +345,20 @@ __global__ void k_out_bwd_pre(const float* __restrict__ dlog, const float* __res
 
 __global__ __launch_bounds__(256) void k_out_bwd_w(const float* __restrict__ dlog, const float* __restrict__ F1r,
                                                    const float* __restrict__ D2, int R, float* __restrict__ dWo,
-                                                   float* __restrict__ dbo, float* __restrict__ clear, int n_clear) {
+                                                   float* __restrict__ dbo, float* __restrict__ clear, int n_clear,
+                                                   const float* __restrict__ loss_rows, float* __restrict__ loss) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_clear; i += 64 * 256) clear[i] = 0.f;
+    if (loss && blockIdx.x == 63) {                          // the forward's loss rows, added in row order as k_loss_sum does
+        __shared__ float s_l[1024];
+        float s = 0.f;
+        for (int base = 0; base < R; base += 1024) {
+            for (int i = threadIdx.x; i < 1024 && base + i < R; i += 256) s_l[i] = loss_rows[base + i];
+            __syncthreads();
+            if (threadIdx.x == 0) { const int m = min(1024, R - base); for (int r = 0; r < m; ++r) s += s_l[r]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *loss = s;
+    }
     int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;       // 64 blocks x 4 waves = 256 columns
     float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
     for (int r = lane; r < R; r += 64) {
@@ -359,47 +371,50 @@ __global__ __launch_bounds__(256) void k_out_bwd_w(const float* __restrict__ dlo
 }
 
 extern "C" int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
-                               float* dWo, float* dbo, float* clear, int n_clear, void* stream) {
-    if (!dlog || !Wo || !F1r || !dWo || !dbo || R <= 0 || n_clear < 0 || (n_clear > 0 && !clear)) return EVAD_ERR_ARG;
+                               float* dWo, float* dbo, float* clear, int n_clear, const float* loss_rows, float* loss,
+                               void* stream) {
+    if (!dlog || !Wo || !F1r || !dWo || !dbo || R <= 0 || n_clear < 0 || (n_clear > 0 && !clear) || (loss && !loss_rows)) return EVAD_ERR_ARG;
     if (dPre)
         hipLaunchKernelGGL(k_out_bwd_pre, dim3(evad_blocks((long long)R * 256, 256)), dim3(256), 0, (hipStream_t)stream, dlog, Wo,
                            F1r, D2, R, dPre);
-    hipLaunchKernelGGL(k_out_bwd_w, dim3(64), dim3(256), 0, (hipStream_t)stream, dlog, F1r, D2, R, dWo, dbo, clear, n_clear);
+    hipLaunchKernelGGL(k_out_bwd_w, dim3(64), dim3(256), 0, (hipStream_t)stream, dlog, F1r, D2, R, dWo, dbo, clear, n_clear, loss_rows, loss);
     return evad_last_error();
 }
 
 // column sums (bias gradients): out[n] = sum_r A[r, n]; 64 columns per workgroup, the 4 waves split the
 // rows, fixed-order LDS reduction.
-struct ColGroup { const float* A[8]; float* out[8]; int lda[8], N[8]; int R, n; };
+#define COL_MAXP 12
+struct ColGroup { const float* A[COL_MAXP]; float* out[COL_MAXP]; int lda[COL_MAXP], N[COL_MAXP], R[COL_MAXP]; int n; };
 __global__ __launch_bounds__(256) void k_colsum_g(ColGroup g) {
     __shared__ float red[4][64];
-    int pi = blockIdx.y, N = g.N[pi];
+    const int pi = blockIdx.y, N = g.N[pi], R = g.R[pi];
     int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     if (blockIdx.x * 64 >= N) return;
     float s = 0.f;
     if (n < N) {
         const float* a = g.A[pi] + n; const size_t ld = (size_t)g.lda[pi];
         int r = w;
-        for (; r + 28 < g.R; r += 32) {                      // 8 rows in flight, added in row order
+        for (; r + 28 < R; r += 32) {                        // 8 rows in flight, added in row order
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = a[(size_t)(r + 4 * u) * ld];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; r < g.R; r += 4) s += a[(size_t)r * ld];
+        for (; r < R; r += 4) s += a[(size_t)r * ld];
     }
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
     if (w == 0 && n < N) g.out[pi][n] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-/* desc: HOST array, 4 int64 per problem: [0] A [1] out [2] lda [3] N; all problems have R rows. */
+/* desc: HOST array, 5 int64 per problem: [0] A [1] out [2] lda [3] N [4] rows (0 = R, the call's common row count). */
 extern "C" int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream) {
-    if (n < 1 || n > 8 || !desc || R <= 0) return EVAD_ERR_ARG;
-    ColGroup g; g.n = n; g.R = R; int nmax = 0;
+    if (n < 1 || n > COL_MAXP || !desc || R <= 0) return EVAD_ERR_ARG;
+    ColGroup g; g.n = n; int nmax = 0;
     for (int i = 0; i < n; ++i) {
-        g.A[i] = (const float*)desc[4 * i]; g.out[i] = (float*)desc[4 * i + 1]; g.lda[i] = (int)desc[4 * i + 2]; g.N[i] = (int)desc[4 * i + 3];
+        const int64_t* d = desc + 5 * i;
+        g.A[i] = (const float*)d[0]; g.out[i] = (float*)d[1]; g.lda[i] = (int)d[2]; g.N[i] = (int)d[3]; g.R[i] = d[4] > 0 ? (int)d[4] : R;
         if (!g.A[i] || !g.out[i] || g.N[i] <= 0 || g.lda[i] < g.N[i]) return EVAD_ERR_ARG;
         if (g.N[i] > nmax) nmax = g.N[i];
     }
@@ -411,8 +426,10 @@ extern "C" int eventad_colsum_group(int n, const int64_t* desc, int R, void* str
 // ------------------------------------------------------------------------------------------------
 // Optimiser: clip_grad_norm_(max_norm) + AdamW on flat fp32 buffers (utils/train.py:27-53,141-152).
 //   state[0]=step  [1]=grad norm  [2]=clip coefficient  [3]=1-beta1^t  [4]=1-beta2^t  [5]=non-finite count  [6]=this update was skipped
+//   [7]=step count of the update in flight ([3], [4] belong to it)
 #define NORM_BLOCKS 256
-__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, int n, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, int n, float* __restrict__ partial,
+                                                        double beta1, double beta2, float* __restrict__ state) {
     __shared__ float red[256];
     float s = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += NORM_BLOCKS * 256) s += g[i] * g[i];
@@ -420,39 +437,45 @@ __global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict_
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {               // what the update needs if it is not skipped: the next step count
+        const float step = state[0] + 1.f;                   // ([7], committed to [0] by k_adamw) and its bias corrections
+        state[7] = step;
+        state[3] = (float)(1.0 - pow(beta1, (double)step)); state[4] = (float)(1.0 - pow(beta2, (double)step));
+    }
 }
 
-__global__ __launch_bounds__(64) void k_opt_prepare(const float* __restrict__ partial, float max_norm, double beta1, double beta2, float* __restrict__ state) {
-    // 256 partial sums: 4 per lane (independent loads), then a fixed shuffle tree -- reproducible
-    const int lane = threadIdx.x;
-    float s = (partial[lane] + partial[64 + lane]) + (partial[128 + lane] + partial[192 + lane]);
+// Every workgroup adds up the 256 partial sums itself (4 per lane of its first wave, then a fixed shuffle tree: the same
+// bits in every workgroup and every run) instead of waiting for a one-wave launch that does it once.
+//   The reference raises on a non-finite gradient BEFORE optimizer.step() (utils/train.py:144-149), so its weights stay
+//   clean; and a batch without any valid object leaves every p.grad None, which AdamW skips entirely.  Both cases become a
+//   skipped update here: parameters, moments and the step count stay as they are ([6] = 1), the non-finite case is also
+//   counted in [5] for the host's lazy check.
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
+                                               float lr, float beta1, float omb1, float beta2, float omb2, float eps, float decay,
+                                               float max_norm, const float* __restrict__ partial, float* __restrict__ state) {
+    __shared__ float s_norm;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        float s = (partial[lane] + partial[64 + lane]) + (partial[128 + lane] + partial[192 + lane]);
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-    if (lane != 0) return;
-    float norm = sqrtf(s);
-    state[1] = norm;
-    // The reference raises on a non-finite gradient BEFORE optimizer.step() (utils/train.py:144-149), so its weights
-    // stay clean; and a batch without any valid object leaves every p.grad None, which AdamW skips entirely.  Both
-    // cases become a skipped update here: parameters, moments and the step count stay as they are ([6] = 1), the
-    // non-finite case is also counted in [5] for the host's lazy check.
-    const bool finite = isfinite(norm);
-    if (!finite) state[5] += 1.f;
-    if (!finite || norm == 0.f) { state[6] = 1.f; state[2] = 1.f; return; }
-    state[6] = 0.f;
-    float step = state[0] + 1.f;
-    state[0] = step;
+        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) s_norm = sqrtf(s);
+    }
+    __syncthreads();
+    const float norm = s_norm;
+    const bool finite = isfinite(norm), skip = !finite || norm == 0.f;
     float coef = max_norm / (norm + 1e-6f);                 // torch.nn.utils.clip_grad_norm_
-    state[2] = coef < 1.f ? coef : 1.f;
-    state[3] = (float)(1.0 - pow(beta1, (double)step)); state[4] = (float)(1.0 - pow(beta2, (double)step));
-}
-
-__global__ void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
-                        float lr, float beta1, float omb1, float beta2, float omb2, float eps, float decay,
-                        const float* __restrict__ state) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    coef = coef < 1.f ? coef : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state[1] = norm;
+        if (!finite) state[5] += 1.f;
+        state[6] = skip ? 1.f : 0.f; state[2] = skip ? 1.f : coef;
+        if (!skip) state[0] = state[7];
+    }
+    if (skip) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (state[6] != 0.f) return;                            // skipped update (see k_opt_prepare)
-    float gi = g[i] * state[2];
+    float gi = g[i] * coef;
     g[i] = gi;                                              // grads are left clipped, as clip_grad_norm_ does
     float pi = p[i] * decay;
     float mi = beta1 * m[i] + omb1 * gi;
@@ -467,11 +490,10 @@ extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, f
                                   float* partial, float* state, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !partial || !state || n <= 0) return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sqnorm_partial, dim3(NORM_BLOCKS), dim3(256), 0, st, grads, n, partial);
-    hipLaunchKernelGGL(k_opt_prepare, dim3(1), dim3(64), 0, st, partial, (float)max_norm, beta1, beta2, state);
+    hipLaunchKernelGGL(k_sqnorm_partial, dim3(NORM_BLOCKS), dim3(256), 0, st, grads, n, partial, beta1, beta2, state);
     hipLaunchKernelGGL(k_adamw, dim3(evad_blocks(n, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (float)lr,
                        (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)(1.0 - lr * weight_decay), state);
+                       (float)(1.0 - lr * weight_decay), (float)max_norm, partial, state);
     return evad_last_error();
 }
 

@@ -220,8 +220,12 @@ class NativeHead:
         self._gg((0, 1, w["H1n"], 256, P[fu + "event_proj.weight"], 256, w["ZCAT"], 512, R, 256, 256, P[fu + "event_proj.bias"]),
                  (0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, P[fu + "coord_proj.bias"]))
         self._gg((0, 1, w["ZCAT"], 512, P[fu + "fusion.0.weight"], 512, w["F1r"], 256, R, 256, 512, P[fu + "fusion.0.bias"], 1))
+        # a training loop (lean) reads the loss after the step: its rows are then added by the first launch of backward()
+        # instead of a launch of their own here
+        self._loss_deferred = bool(lean and train)
         call("eventad_fuse_out", ptr(w["F1r"]), _rp(self.D2), _rp(P[fu + "fusion.3.weight"]), _rp(P[fu + "fusion.3.bias"]),
-             ptr(w["target"]), ptr(w["valid"]), R, ptr(w["logits"]), ptr(w["dlog"]), ptr(w["loss_rows"]), ptr(w["loss"]),
+             ptr(w["target"]), ptr(w["valid"]), R, ptr(w["logits"]), ptr(w["dlog"]), ptr(w["loss_rows"]),
+             None if self._loss_deferred else ptr(w["loss"]),
              ptr(w["dPre"]), st)                               # dPre: the first step of backward(), while the rows are in registers
         self._fw = (B, train)
         if lean:                                               # training loop: no dtype conversions (3 launches less)
@@ -272,8 +276,11 @@ class NativeHead:
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
         # every used gradient entry is written (not accumulated) below; the attention vectors accumulate over the clips in
         # small buffers of their own (cleared here), the alignment pads of the flat buffer are zero from allocation
+        deferred = getattr(self, "_loss_deferred", False)
         call("eventad_out_bwd", ptr(w["dlog"]), _rp(P[fu + "fusion.3.weight"]), ptr(w["F1r"]), _rp(self.D2), R, None,
-             _rp(G[fu + "fusion.3.weight"]), _rp(G[fu + "fusion.3.bias"]), ptr(w["dwatt"]), w["dwatt"].numel(), st)
+             _rp(G[fu + "fusion.3.weight"]), _rp(G[fu + "fusion.3.bias"]), ptr(w["dwatt"]), w["dwatt"].numel(),
+             ptr(w["loss_rows"]) if deferred else None, ptr(w["loss"]) if deferred else None, st)
+        self._loss_deferred = False
         dE, dC = w["dZCAT"], w["dZCAT"][:, 256:]
         self._gg((1, 0, w["dPre"], 256, w["ZCAT"], 512, G[fu + "fusion.0.weight"], 512, 256, 512, R),
                  (0, 0, w["dPre"], 256, P[fu + "fusion.0.weight"], 512, w["dZCAT"], 512, R, 512, 256))
@@ -281,8 +288,8 @@ class NativeHead:
                  (0, 0, dE, 512, P[fu + "event_proj.weight"], 256, w["dH1o"], 256, R, 256, 256),
                  (1, 0, dC, 512, w["HCn"], 32, G[fu + "coord_proj.weight"], 32, 256, 32, R),
                  (0, 0, dC, 512, P[fu + "coord_proj.weight"], 32, w["dHCo"], 32, R, 32, 256))
-        self._desc("eventad_colsum_group", 4, [[w["dPre"], G[fu + "fusion.0.bias"], 256, 256], [dE, G[fu + "event_proj.bias"], 512, 256],
-                                               [dC, G[fu + "coord_proj.bias"], 512, 256]], R)
+        # (the bias gradients of these three layers are column sums of dPre / dZCAT, which stay as they are until the end
+        # of backward(): they ride in its last column-sum launch)
         # dS of the state after the last clip is zero: a constant zero buffer read by the first stage of each chain
         # (z* are never written), then the a/b buffers alternate
         d0, d1, dc = w["zero256"], w["zero256"], w["zero32"]
@@ -342,7 +349,6 @@ class NativeHead:
         # [dwatt0 | dwattc] + [dwatt1 | 0] lands on both with one launch
         o = self.off["soft_attention.weight"]
         assert self.off["soft_attention_cor.weight"] == o + 256
-        torch.add(w["dwatt"][:288], w["dwatt"][288:], out=self.grads[o:o + 288])
         # weight gradients of the recurrent layers, batched over all clips: ONE launch (+ one reduce)
         self._gg((1, 0, w["dGI0"], 768, w["X"], 64, G[ev + "weight_ih_l0"], 64, 768, 64, R),
                  (1, 0, w["dGH0"], 768, w["S0"], 256, G[ev + "weight_hh_l0"], 256, 768, 256, R),
@@ -350,10 +356,14 @@ class NativeHead:
                  (1, 0, w["dGH1"], 768, w["S1"], 256, G[ev + "weight_hh_l1"], 256, 768, 256, R),
                  (1, 0, w["dGIC"], 96, w["CO"], 4, G[co + "weight_ih_l0"], 4, 96, 4, R),
                  (1, 0, w["dGHC"], 96, w["SC"], 32, G[co + "weight_hh_l0"], 32, 96, 32, R))
-        self._desc("eventad_colsum_group", 4,
-                   [[w["dGI0"], G[ev + "bias_ih_l0"], 768, 768], [w["dGH0"], G[ev + "bias_hh_l0"], 768, 768],
-                    [w["dGI1"], G[ev + "bias_ih_l1"], 768, 768], [w["dGH1"], G[ev + "bias_hh_l1"], 768, 768],
-                    [w["dGIC"], G[co + "bias_ih_l0"], 96, 96], [w["dGHC"], G[co + "bias_hh_l0"], 96, 96]], R)
+        # every bias gradient of the head (a column sum over the R rows) in one launch, together with the attention vectors:
+        # [dwatt0 | dwattc] + [dwatt1 | 0] is the column sum of the accumulator seen as a 2-row matrix
+        self._desc("eventad_colsum_group", 5,
+                   [[w["dGI0"], G[ev + "bias_ih_l0"], 768, 768, 0], [w["dGH0"], G[ev + "bias_hh_l0"], 768, 768, 0],
+                    [w["dGI1"], G[ev + "bias_ih_l1"], 768, 768, 0], [w["dGH1"], G[ev + "bias_hh_l1"], 768, 768, 0],
+                    [w["dGIC"], G[co + "bias_ih_l0"], 96, 96, 0], [w["dGHC"], G[co + "bias_hh_l0"], 96, 96, 0],
+                    [w["dPre"], G[fu + "fusion.0.bias"], 256, 256, 0], [dE, G[fu + "event_proj.bias"], 512, 256, 0],
+                    [dC, G[fu + "coord_proj.bias"], 512, 256, 0], [w["dwatt"], self.grads[o:o + 288], 288, 288, 2]], R)
 
     def _backward_chain_fused(self, B, train):
         """The reverse recurrence with one launch per stage (eventad_head_stage_bwd): stage b runs GRU layer 1 and the

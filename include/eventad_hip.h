@@ -274,8 +274,10 @@ int eventad_fuse_out(const float* F1r, const float* D2, const float* Wo, const f
                      const int32_t* valid, int R, float* logits, float* dlog, float* loss_rows, float* loss, float* dPre,
                      void* stream);
 int eventad_out_bwd(const float* dlog, const float* Wo, const float* F1r, const float* D2, int R, float* dPre,
-                    float* dWo, float* dbo, float* clear, int n_clear, void* stream);
-/* up to 8 column sums per launch; desc = HOST array, 4 int64 per problem: [0] A [1] out [2] lda [3] N */
+                    float* dWo, float* dbo, float* clear, int n_clear, const float* loss_rows /* nullable */,
+                    float* loss /* nullable: adds up loss_rows in row order, for an eventad_fuse_out call made with loss = NULL */,
+                    void* stream);
+/* up to 12 column sums per launch; desc = HOST array, 5 int64 per problem: [0] A [1] out [2] lda [3] N [4] rows (0 = R) */
 int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream);
 /* clip_grad_norm_ + AdamW on flat buffers (utils/train.py:27-53,141-152).  state f32[8]:
  * [0] step, [1] grad norm, [2] clip coefficient, [3] 1-beta1^t, [4] 1-beta2^t, [5] non-finite-norm count, [6] 1 if this
