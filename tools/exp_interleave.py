@@ -11,7 +11,8 @@ W, H, n, B, live = synthetic.CONFIGS[cfg]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else B            # clips per backbone pass (default: the configuration's batch)
 dev = torch.device("cuda:0")
 graphs, keep = [], []
-for i in range(2):
+NG = int(sys.argv[3]) if len(sys.argv) > 3 else 2           # graphs (= streams) in flight
+for i in range(NG):
     args, model, sd = bench.build_model(W, H, B, dev, live_cnn=live)
     model.train()
     data = format_data(synthetic.make_config_batch(cfg, first_clip=B * i, batch_size=B).to(dev))
@@ -23,7 +24,7 @@ for i in range(2):
         with torch.cuda.graph(g):
             f = model.extract_features(data, frames=(1,))
     graphs.append(g); keep.append((model, data, f))
-s = [torch.cuda.Stream(), torch.cuda.Stream()]
+s = [torch.cuda.Stream() for _ in range(NG)]
 E = lambda: torch.cuda.Event(enable_timing=True)
 def run(which, reps=40):
     torch.cuda.synchronize()
@@ -41,4 +42,4 @@ def run(which, reps=40):
     torch.cuda.synchronize()
     return a.elapsed_time(b) / (reps * len(which))
 for _ in range(2):
-    print("%d clips per pass -- one chain: %.3f ms per pass; two interleaved chains: %.3f ms per pass" % (B, run([0]), run([0, 1])))
+    print("%d clips per pass -- one chain: %.3f ms per pass; %d interleaved chains: %.3f ms per pass" % (B, run([0]), NG, run(list(range(NG)))))
