@@ -74,14 +74,16 @@ extern "C" int eventad_ell_transpose(const int32_t* ell_src, const int32_t* deg,
 // ------------------------------------------------------------------------------------------------ dL/dx
 // One quad per source; lane q of the quad owns input channels {4q..4q+3} (+ 16+q for Cin = 20), exactly as the forward
 // kernel, and reads its rows of LUT[cell] (row order [i][j], see eventad_amd/spline.py::quad_row_order) from LDS.
-template <int CINP>
+template <int CINP, bool LUT_IN_LDS>      // LUT_IN_LDS = false (search radii whose table exceeds LDS): rows are read from memory
 __global__ __launch_bounds__(256) void k_conv_bwd_data(const float* __restrict__ g, const unsigned* __restrict__ out_start,
                                                        const int* __restrict__ out_edge, const uint16_t* __restrict__ ell_step,
                                                        const float* __restrict__ lut, float* __restrict__ dx, int N, int steps) {
     extern __shared__ __attribute__((aligned(16))) float s_lut[];
     constexpr int KL = CINP == 20 ? 5 : 4, LS = CINP * 16;
-    for (int t = threadIdx.x; t < (steps + 1) * LS / 4; t += 256) ((float4*)s_lut)[t] = ((const float4*)lut)[t];
-    __syncthreads();
+    if (LUT_IN_LDS) {
+        for (int t = threadIdx.x; t < (steps + 1) * LS / 4; t += 256) ((float4*)s_lut)[t] = ((const float4*)lut)[t];
+        __syncthreads();
+    }
     const int j = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
     if (j >= N) return;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void k_conv_bwd_data(const float* __restrict__
         const float4* gr = (const float4*)(g + (size_t)i * 16);
         const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3];
         const float gv[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
-        const float* w = s_lut + cell * LS + q * 16;
+        const float* w = (LUT_IN_LDS ? s_lut : lut) + cell * LS + q * 16;
 #pragma unroll
         for (int k = 0; k < KL; ++k) {
             float s = 0.f;
@@ -108,23 +110,29 @@ __global__ __launch_bounds__(256) void k_conv_bwd_data(const float* __restrict__
 }
 
 // lut f32[steps+1][Cin_pad][16] in the [i][j] row order of the forward kernel (row `steps` = self-edge matrix); g f32[N,16];
-// dx f32[N, Cin_pad].  cin_pad = 20 or 16.  (steps + 1) * Cin_pad * 64 bytes of LDS: radius <= 5 px.
+// dx f32[N, Cin_pad].  cin_pad = 20 or 16.  The table is staged in LDS when its (steps + 1) * Cin_pad * 64 bytes fit in 150 KB
+// (radius <= 4 / 5 px), else read from memory.
 extern "C" int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_start, const int32_t* out_edge, const uint16_t* ell_step,
                                         const float* lut, float* dx, int N, int steps, int cin_pad, void* stream) {
     if (!g || !out_start || !out_edge || !ell_step || !lut || !dx || N < 0 || steps < 1 || (cin_pad != 20 && cin_pad != 16)) return EVAD_ERR_ARG;
     const size_t lds = sizeof(float) * (size_t)(steps + 1) * cin_pad * 16;
-    if (lds > 150 * 1024) return EVAD_ERR_ARG;             // larger search radii: not implemented for the backward pass
     if (N == 0) return EVAD_OK;
     hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(evad_blocks(N, 64)), block(256);
+    if (lds > 150 * 1024) {                                  // the table does not fit in LDS: read its rows from memory (L2)
+        if (cin_pad == 20) hipLaunchKernelGGL((k_conv_bwd_data<20, false>), grid, block, 0, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
+        else               hipLaunchKernelGGL((k_conv_bwd_data<16, false>), grid, block, 0, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
+        return evad_last_error();
+    }
     static size_t attr[2] = {0, 0};
     if (cin_pad == 20) {
-        auto kern = k_conv_bwd_data<20>;
+        auto kern = k_conv_bwd_data<20, true>;
         if (attr[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
-        hipLaunchKernelGGL(kern, dim3(evad_blocks(N, 64)), dim3(256), lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
     } else {
-        auto kern = k_conv_bwd_data<16>;
+        auto kern = k_conv_bwd_data<16, true>;
         if (attr[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
-        hipLaunchKernelGGL(kern, dim3(evad_blocks(N, 64)), dim3(256), lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
     }
     return evad_last_error();
 }

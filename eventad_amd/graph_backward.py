@@ -5,7 +5,7 @@ scatter-add (src/dagr/model/layers/spline_conv.py:39-78); EventAD itself freezes
 so nothing here runs in its training step.
 
 Host logic only: workspace, the launch sequence, and the (linear, tiny) map from the per-spiral-step gradient dLUT back to
-dL/d weight[25, Cin, 16] and dL/d root, done by autograd over the same torch expression that builds the LUT."""
+dL/d weight[25, Cin, 16] and dL/d root: the transpose of the blend that builds the LUT, as one small matrix product."""
 import torch
 
 from . import spline
@@ -49,10 +49,9 @@ class EventConvBackward:
         -> (dx f32[N, cin_pad], dweight f32[25, Cin, 16], droot f32[16, Cin])."""
         cin_pad, steps = int(x.shape[1]), self.geom.steps
         st = torch.cuda.current_stream().cuda_stream
-        w_cpu = weight.detach().float().cpu().requires_grad_(True)
-        r_cpu = root.detach().float().cpu().requires_grad_(True)
-        full = self._full_lut(w_cpu, r_cpu, cin_pad)                             # differentiable, ~50 x 320 floats
-        lut_dev = spline.quad_row_order(full.detach()).to(self.dev)
+        cin = int(weight.shape[1])
+        full = self._full_lut(weight.detach().float().cpu(), root.detach().float().cpu(), cin_pad)
+        lut_dev = spline.quad_row_order(full).to(self.dev)
         x, g = x.contiguous(), g.contiguous()
         dx = torch.empty((N, cin_pad), device=self.dev)
         call("eventad_l1_conv_bwd_data", ptr(g), ptr(self.out_start), ptr(self.out_edge), ptr(ws["ell_step"]), ptr(lut_dev), ptr(dx),
@@ -61,7 +60,15 @@ class EventConvBackward:
         dlut = torch.empty((steps + 1, cin_pad, 16), device=self.dev)
         call("eventad_l1_conv_bwd_weight", ptr(x), ptr(g), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(partial),
              ptr(dlut), N, steps, cin_pad, st)
-        dw, dr = torch.autograd.grad(full, (w_cpu, r_cpu), dlut.cpu())          # the LUT is linear in (weight, root)
+        # The LUT is linear in (weight, root): LUT[s] = sum_c blend[s, c] W_c, row `steps` = LUT[0] + root.  Its transpose as
+        # one float64 product (autograd's index-accumulate over the 4 taps of 225 steps was not run-to-run reproducible).
+        if getattr(self, "_blend", None) is None:
+            self._blend = spline.lut_by_spiral_step(torch.eye(25).view(25, 25, 1), self.geom, 25)[:, :, 0].double()   # [steps, 25]
+        dl = dlut.cpu().double()
+        d = dl[:steps].clone()
+        d[0] += dl[steps]
+        dw = (self._blend.t() @ d.reshape(steps, -1)).reshape(25, cin_pad, 16)[:, :cin].float().contiguous()
+        dr = dl[steps][:cin].t().float().contiguous()
         return dx, dw, dr
 
 

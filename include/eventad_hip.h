@@ -329,8 +329,8 @@ int eventad_ell_transpose(const int32_t* ell_src, const int32_t* deg, int N, uin
                           uint32_t* cnt, uint32_t* scan_tmp, uint16_t* arrival, int32_t* tmp, void* stream);
 /* dx_j = sum over out-edges (j -> i) of LUT[cell] g_i.  g f32[N,16] = dL/d(conv output); lut f32[steps+1][cin_pad][16] with
  * the input-channel rows in the forward kernel's [i][j] order, row `steps` = self-edge matrix; dx f32[N, cin_pad];
- * cin_pad = 20 or 16; (steps+1) * cin_pad * 64 bytes must fit in 150 KB of LDS (search radius <= 4 px for cin_pad = 20,
- * <= 5 px for 16), else -1. */
+ * cin_pad = 20 or 16; the table is staged in LDS when its (steps+1) * cin_pad * 64 bytes fit in 150 KB (search radius <= 4 px
+ * for cin_pad = 20, <= 5 px for 16), else its rows are read from memory. */
 int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_start, const int32_t* out_edge, const uint16_t* ell_step,
                              const float* lut, float* dx, int N, int steps, int cin_pad, void* stream);
 /* dlut[c] = sum over edges with spiral step c of x_src (x) g_dst, f32[steps+1][cin_pad][16] in natural channel order (row

@@ -10,8 +10,10 @@ from eventad_amd import synthetic, weights
 pytestmark = pytest.mark.gpu
 
 
-# 320x240: search radius 4 px, 81 spiral steps -- both kernels then ask for more than 64 KB of dynamic LDS
-@pytest.mark.parametrize("W,H,n,B,span", [(64, 64, 3000, 2, 50000), (256, 256, 20000, 2, 50000), (64, 64, 20000, 1, 20000), (320, 240, 12000, 2, 30000)])
+# 320x240: search radius 4 px, 81 spiral steps -- both kernels then ask for more than 64 KB of dynamic LDS; 640x480: radius 7,
+# 225 steps -- the data gradient reads the table from memory, the weight gradient sorts 226 bins in 140 KB of LDS
+@pytest.mark.parametrize("W,H,n,B,span", [(64, 64, 3000, 2, 50000), (256, 256, 20000, 2, 50000), (64, 64, 20000, 1, 20000), (320, 240, 12000, 2, 30000),
+                                          (640, 480, 30000, 2, 12000)])
 def test_event_conv_backward_matches_autograd(W, H, n, B, span):
     from oracle import dagr_ref
     from eventad_amd.backbone import NativeBackbone

@@ -112,7 +112,8 @@ def test_csr_transpose_lists_every_edge_once_in_order():
     assert torch.equal(edge_dst.cpu().long(), torch.repeat_interleave(torch.arange(n), deg))
 
 
-@pytest.mark.parametrize("W,H,n,B,span,seed", [(64, 64, 3000, 2, 50000, 15), (96, 64, 6000, 3, 20000, 17), (256, 256, 20000, 2, 50000, 16)])
+@pytest.mark.parametrize("W,H,n,B,span,seed", [(64, 64, 3000, 2, 50000, 15), (96, 64, 6000, 3, 20000, 17), (256, 256, 20000, 2, 50000, 16),
+                                               (640, 480, 20000, 2, 12000, 18)])      # search radius 7 px: table of the data gradient in memory
 def test_whole_graph_branch_backward_matches_autograd(W, H, n, B, span, seed):
     """out3 / out4 cotangents -> gradients of all 25 weight tensors of the five Layers and of the five CNN maps, against
     autograd through the oracle's whole Net.forward (same mask precondition as above, here also for Layer 1)."""
