@@ -16,6 +16,7 @@ batch k: overlapping them changes nothing but the wall clock.  There is no CPU p
 import os
 
 import torch
+import torch.distributed as dist
 
 from .ddp import GradSync
 
@@ -288,6 +289,11 @@ class TrainStep:
                 b.record()
                 torch.cuda.synchronize()
                 t.append(a.elapsed_time(b) / 3)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # every rank must take the same decision (it fixes the number of chains): use the slowest rank's times
+                tt = torch.tensor(t, device=in_h[0].bbox.device, dtype=torch.float32)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t = [float(v) for v in tt.cpu()]
             d["graph_ms"] = tuple(t)
             # C2: head 0.41 ms against 0.82 ms (ratio 0.5; the partition + three chains give 0.68 ms per step against 0.88
             # without); C3 / C4 / C5: ratios 0.16 / 0.02 / 0.03, where taking CUs from the backbone only costs
