@@ -54,6 +54,8 @@ class NativeBackbone:
         # who fills pool1's neighbour bitmap: True = the wave-per-voxel pooling kernel (no atomics; default),
         # "edge_search" = the edge search while the ELL row is in registers (atomics), False = a pass of its own over the ELL
         self.fused_mark = True
+        # the last blend of a pooled Layer also scatters its rows into the next level's voxel table (one launch per level less)
+        self.fused_blend_pool = os.environ.get("EVENTAD_FUSED_BLEND_POOL", "1") != "0"
         self._tail_arena_clean = False
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         self.load_weights(state_dict)
@@ -352,6 +354,7 @@ class NativeBackbone:
         else:
             ws["tail_arena"].zero_()
         out3 = None
+        fused = self.fused_blend_pool                        # a Layer's last blend also scatters into the next level's voxel table
         for lv in range(4):
             L = view[lv]
             if lv > 0:
@@ -359,7 +362,11 @@ class NativeBackbone:
                 vsx, vsy = g.voxel[lv]
                 mean = 1 if g.pool_aggr[lv] == "mean" else 0
                 fmap = tail_maps[lv - 1]
-                self._c("eventad_pool_scatter", _rp(Lp.y), 64, 64, _rp(fmap), fmap.shape[1], fmap.shape[2], 64,
+                if fused and mean:
+                    self._c("eventad_pool_mean_gather", _rp(Lp.y), 64, 64, _rp(fmap), fmap.shape[1], fmap.shape[2], 64, _rp(Lp.npos),
+                            _rp(Lp.nbatch), ptr(Lp.node_slot_in), Lp.n_max, _rp(Lp.n_dev), g.W, g.H, L.nx, L.ny, B, ptr(L.feat), st)
+                if not fused:
+                  self._c("eventad_pool_scatter", _rp(Lp.y), 64, 64, _rp(fmap), fmap.shape[1], fmap.shape[2], 64,
                      _rp(Lp.npos), _rp(Lp.npix), _rp(Lp.nbatch), None, None, Lp.n_max, _rp(Lp.n_dev), g.W, g.H, vsx, vsy,
                      L.nx, L.ny, B, mean, ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx),
                      ptr(Lp.node_slot_in), ptr(ws["flags_tail"]), 1, _rp(Lp.rowptr), _rp(Lp.csr_src), ptr(L.bitmap), st)   # + edge marks
@@ -385,9 +392,20 @@ class NativeBackbone:
                  L.n_max, _rp(L.n_dev), dvx, dvy, ptr(t["bn1"][0]), ptr(t["bn1"][1]), None, None, ptr(L.y1), 64, st)
             self._c("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, _rp(L.n_dev),
                  26 * 64, 64, None, None, None, None, 0, 0, st)
-            self._c("eventad_tail_blend", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, _rp(L.rowptr), _rp(L.csr_src),
-                 _rp(L.csr_dxy), L.n_max, _rp(L.n_dev), dvx, dvy, ptr(t["bn2"][0]), ptr(t["bn2"][1]), ptr(t["bns"][0]),
-                 ptr(t["bns"][1]), ptr(L.y), 64, st)
+            if fused and lv < 3:
+                Ln = view[lv + 1]
+                nvx, nvy = g.voxel[lv + 1]
+                nmap = tail_maps[lv]
+                self._c("eventad_tail_blend_pool", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, _rp(L.rowptr), _rp(L.csr_src),
+                     _rp(L.csr_dxy), L.n_max, _rp(L.n_dev), dvx, dvy, ptr(t["bn2"][0]), ptr(t["bn2"][1]), ptr(t["bns"][0]),
+                     ptr(t["bns"][1]), ptr(L.y), 64, _rp(nmap), nmap.shape[1], nmap.shape[2], _rp(L.npos), _rp(L.npix),
+                     _rp(L.nbatch), g.W, g.H, nvx, nvy, Ln.nx, Ln.ny, B, 1 if g.pool_aggr[lv + 1] == "mean" else 0, ptr(Ln.feat),
+                     ptr(Ln.sums), ptr(Ln.tsum), ptr(Ln.cnt), ptr(Ln.maxidx), ptr(L.node_slot_in), ptr(ws["flags_tail"]),
+                     ptr(Ln.bitmap), st)
+            else:
+                self._c("eventad_tail_blend", ptr(L.z2), 26 * 64, 25, ptr(L.z1), 27 * 64, 26, _rp(L.rowptr), _rp(L.csr_src),
+                     _rp(L.csr_dxy), L.n_max, _rp(L.n_dev), dvx, dvy, ptr(t["bn2"][0]), ptr(t["bn2"][1]), ptr(t["bns"][0]),
+                     ptr(t["bns"][1]), ptr(L.y), 64, st)
             if lv == 2:
                 out3 = dict(x=L.y, pos=L.npos, batch=L.nbatch, n_dev=L.n_dev, level=L)
         L = view[3]

@@ -73,16 +73,7 @@ extern "C" int eventad_csr_transpose(const uint32_t* rowptr, const int32_t* csr_
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise pieces
-// same basis as tail.hip::basis1 (torch_spline_conv degree-1 open spline, kernel size 5)
-__device__ __forceinline__ void bp_basis1(float attr, int* i0, int* i1, float* b0, float* b1) {
-    float v = __fmul_rn(attr, 4.f);
-    int t = (int)v;
-    float fr = __fsub_rn(v, floorf(v));
-    int a = t % 5, b = (t + 1) % 5;
-    *i0 = a < 0 ? a + 5 : a; *i1 = b < 0 ? b + 5 : b;
-    *b0 = __fsub_rn(1.f, fr);
-    *b1 = __fadd_rn(__fsub_rn(__fsub_rn(1.f, fr), 1.f), __fmul_rn(2.f, fr));
-}
+// (basis: evad_basis1, common.h -- the forward's)
 
 // out_a = g * [y > 0] * scale_a (, out_b = g * [y > 0] * scale_b): through the ReLU and the folded BatchNorm scale(s)
 __global__ void k_relu_scale_bwd(const float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy, const float* __restrict__ sa,
@@ -121,8 +112,8 @@ __global__ __launch_bounds__(256) void k_tail_blend_bwd(const float* __restrict_
         const int dx = (int)(short)(pk & 0xffff), dy = pk >> 16;
         const float ax = __fadd_rn(__fdiv_rn((float)dx, div_x), 0.5f), ay = __fadd_rn(__fdiv_rn((float)dy, div_y), 0.5f);
         int ix0, ix1, iy0, iy1; float bx0, bx1, by0, by1;
-        bp_basis1(ax, &ix0, &ix1, &bx0, &bx1);
-        bp_basis1(ay, &iy0, &iy1, &by0, &by1);
+        evad_basis1(ax, &ix0, &ix1, &bx0, &bx1);
+        evad_basis1(ay, &iy0, &iy1, &by0, &by1);
         const float v = d[(size_t)i * ldd + c];
         s_acc[w][ix0 + 5 * iy0][c] += __fmul_rn(bx0, by0) * v;
         s_acc[w][ix1 + 5 * iy0][c] += __fmul_rn(bx1, by0) * v;

@@ -95,6 +95,86 @@ __global__ __launch_bounds__(256) void k_pool_scatter(
     }
 }
 
+// --------------------------------------------------------------------------- second convolution of a Layer + the next pooling
+// The Layer's output row y (evad_tail_blend_row: blend, BatchNorm, skip, ReLU) goes straight into the next level's voxel
+// table: one wave per node, lane = channel -- y[c] and the sample of map channel c are max-ed into the slot row while the
+// row is in registers, lane 0 keeps the slot statistics, the lanes share the node's in-edges for the pooled-edge marks.
+// Same arithmetic and the same integer atomics as k_tail_blend followed by k_pool_scatter: same results, one launch and
+// one round trip of y less per level.  (mean aggregation: bookkeeping only, k_pool_mean_gather follows.)
+__global__ __launch_bounds__(256) void k_tail_blend_pool(
+    const float* __restrict__ Z, int ldz, int root_col, const float* __restrict__ Zs, int ldzs, int skip_col,
+    const unsigned* __restrict__ rowptr, const int* __restrict__ csr_src, const int* __restrict__ csr_dxy, int n_max,
+    const int* __restrict__ n_dev, float div_x, float div_y, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ sscale, const float* __restrict__ sshift, float* __restrict__ out, int ldo,
+    const float* __restrict__ map, int map_h, int map_w, const float* __restrict__ npos, const int* __restrict__ npix,
+    const int* __restrict__ nbatch, int W, int H, float vsx, float vsy, int nx, int ny, int S, int mean,
+    unsigned* __restrict__ feat, unsigned long long* __restrict__ sums, double* __restrict__ tsum, unsigned* __restrict__ cnt,
+    int* __restrict__ maxidx, int* __restrict__ node_slot, unsigned* __restrict__ flags, unsigned* __restrict__ bitmap) {
+    const int n = min(*n_dev, n_max);
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    if (node >= n) return;
+    const float y = evad_tail_blend_row(Z, ldz, root_col, Zs, ldzs, skip_col, rowptr, csr_src, csr_dxy, node, c, div_x, div_y,
+                                        scale, shift, sscale, sshift);
+    out[(size_t)node * ldo + c] = y;
+    const float px = npos[3 * node], py = npos[3 * node + 1], pt = npos[3 * node + 2];
+    const int b = nbatch[node];
+    bool bad;
+    const int slot = pool_slot_of(px, py, pt, b, vsx, vsy, nx, ny, S, &bad);
+    if (bad && c == 0) atomicOr(flags, EVAD_FLAG_POOL_WINDOW);
+    if (!mean) {
+        unsigned* frow = feat + (size_t)slot * 128;
+        atomicMax(frow + c, evad_f2ord(y));
+        int x0, y0; float fx, fy;
+        evad_bilinear_setup(px, py, (float)W, (float)H, map_w, map_h, &x0, &y0, &fx, &fy);
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        const bool vx0 = x0 >= 0 && x0 < map_w, vx1 = x0 + 1 >= 0 && x0 + 1 < map_w;
+        const bool vy0 = y0 >= 0 && y0 < map_h, vy1 = y0 + 1 >= 0 && y0 + 1 < map_h;
+        const float* p00 = map + ((size_t)b * map_h * map_w + (size_t)y0 * map_w + x0) * 64 + c;
+        float v = 0.f;                                       // the four terms in k_pool_scatter's order
+        if (vx0 && vy0) v += p00[0] * w00;
+        if (vx1 && vy0) v += p00[64] * w01;
+        if (vx0 && vy1) v += p00[(size_t)map_w * 64] * w10;
+        if (vx1 && vy1) v += p00[(size_t)map_w * 64 + 64] * w11;
+        atomicMax(frow + 64 + c, evad_f2ord(v));
+    }
+    if (c == 0) {
+        atomicAdd(&sums[2 * (size_t)slot], (unsigned long long)npix[2 * node]);
+        atomicAdd(&sums[2 * (size_t)slot + 1], (unsigned long long)npix[2 * node + 1]);
+        atomicAdd((unsigned long long*)tsum + slot, (unsigned long long)llrintf(pt * 1099511627776.f));
+        atomicAdd(&cnt[slot], 1u);
+        atomicMax(&maxidx[slot], node + 1);
+        node_slot[node] = slot;
+    }
+    for (unsigned e = rowptr[node] + c; e < rowptr[node + 1]; e += 64) {
+        const int src = csr_src[e];
+        bool sbad;
+        const int ss = pool_slot_of(npos[3 * src], npos[3 * src + 1], npos[3 * src + 2], nbatch[src], vsx, vsy, nx, ny, S, &sbad);
+        evad_mark_edge(ss, slot, nx, ny, bitmap, flags);
+    }
+}
+
+extern "C" int eventad_tail_blend_pool(const float* Z, int ldz, int root_col, const float* Zskip, int ldzs, int skip_col,
+                                       const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,
+                                       const int32_t* n_dev, float div_x, float div_y, const float* bn_scale,
+                                       const float* bn_shift, const float* skip_scale, const float* skip_shift, float* out,
+                                       int ldo, const float* map_nhwc, int map_h, int map_w, const float* npos,
+                                       const int32_t* npix, const int32_t* nbatch, int W, int H, float vsx, float vsy, int nx,
+                                       int ny, int B, int mean_aggr, uint32_t* feat, uint64_t* sums, double* tsum,
+                                       uint32_t* cnt, int32_t* maxidx, int32_t* node_slot, uint32_t* flags, uint32_t* bitmap,
+                                       void* stream) {
+    if (!Z || !rowptr || !csr_src || !csr_dxy || !n_dev || !bn_scale || !bn_shift || !out || n_max < 0 || ldo < 64 ||
+        div_x <= 0 || div_y <= 0 || (Zskip && (!skip_scale || !skip_shift)) || !npos || !npix || !nbatch || !feat || !sums ||
+        !tsum || !cnt || !maxidx || !node_slot || !flags || !bitmap || (!mean_aggr && !map_nhwc) || nx <= 0 || ny <= 0 ||
+        B <= 0 || vsx <= 0 || vsy <= 0)
+        return EVAD_ERR_ARG;
+    if (n_max == 0) return EVAD_OK;
+    hipLaunchKernelGGL(k_tail_blend_pool, dim3(evad_blocks(n_max, 4)), dim3(256), 0, (hipStream_t)stream, Z, ldz, root_col, Zskip,
+                       ldzs, skip_col, rowptr, csr_src, csr_dxy, n_max, n_dev, div_x, div_y, bn_scale, bn_shift, skip_scale,
+                       skip_shift, out, ldo, map_nhwc, map_h, map_w, npos, npix, nbatch, W, H, vsx, vsy, nx, ny,
+                       nx * ny * (B + 1), mean_aggr, feat, (unsigned long long*)sums, tsum, cnt, maxidx, node_slot, flags, bitmap);
+    return evad_last_error();
+}
+
 // --------------------------------------------------------------------------- mean pooling without float atomics
 // pool4 (mean aggregation, <= 140 input nodes per clip): one wave per output slot scans the input nodes
 // in ascending order and adds the members' rows -- the summation order of the reference's scatter-mean
@@ -182,6 +262,20 @@ extern "C" int eventad_pool_scatter(const float* xa, int lda, int Ca, const floa
 }
 
 
+
+// The in-order mean of eventad_pool_scatter's mean path on its own, for a caller that has already filled node_slot and the
+// slot bookkeeping (eventad_tail_blend_pool with mean_aggr = 1).
+extern "C" int eventad_pool_mean_gather(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
+                                        const float* npos, const int32_t* nbatch, const int32_t* node_slot, int n_max,
+                                        const int32_t* n_dev, int W, int H, int nx, int ny, int B, float* feat, void* stream) {
+    if (!xa || !npos || !nbatch || !node_slot || !n_dev || !feat || Ca < 0 || Cm < 0 || Ca + Cm > 128 || Ca + Cm < 1 ||
+        (Cm > 0 && !map_nhwc) || n_max < 0 || nx <= 0 || ny <= 0 || B <= 0)
+        return EVAD_ERR_ARG;
+    const int S = nx * ny * (B + 1);
+    hipLaunchKernelGGL(k_pool_mean_gather, dim3(evad_blocks(S, 4)), dim3(256), 0, (hipStream_t)stream, xa, lda, Ca, map_nhwc, map_h,
+                       map_w, Cm, npos, nbatch, node_slot, n_max, n_dev, W, H, S, feat);
+    return evad_last_error();
+}
 
 // --------------------------------------------------------------------------- level 0 without atomics
 // One wave per voxel slot, two phases per chunk of up to 64 candidate events:

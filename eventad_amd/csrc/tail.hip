@@ -11,18 +11,8 @@
 // as CSR by destination with ascending source id = the reference's edge order inside a destination.
 #include "common.h"
 
-// torch_spline_conv degree-1 basis for one pseudo-coordinate: v = attr*(kernel_size-1);
-// index k_mod in {0,1}: ((int64)v + k_mod) % 5,  weight 1 - frac - k_mod + 2*frac*k_mod.
-__device__ __forceinline__ void basis1(float attr, int* i0, int* i1, float* b0, float* b1) {
-    float v = __fmul_rn(attr, 4.f);
-    int t = (int)v;                                    // truncation, as the (int64_t) cast
-    float fr = __fsub_rn(v, floorf(v));
-    int a = t % 5, b = (t + 1) % 5;
-    *i0 = a < 0 ? a + 5 : a; *i1 = b < 0 ? b + 5 : b;  // advanced indexing wraps negative indices
-    *b0 = __fsub_rn(1.f, fr);
-    *b1 = __fadd_rn(__fsub_rn(__fsub_rn(1.f, fr), 1.f), __fmul_rn(2.f, fr));
-}
-
+// (evad_basis1 and evad_tail_blend_row -- the row arithmetic, shared with the fused blend + pooling kernel of pool.hip --
+// live in common.h)
 __global__ __launch_bounds__(256) void k_tail_blend(const float* __restrict__ Z, int ldz, int root_col,
                                                     const float* __restrict__ Zs, int ldzs, int skip_col,
                                                     const unsigned* __restrict__ rowptr, const int* __restrict__ csr_src,
@@ -34,54 +24,8 @@ __global__ __launch_bounds__(256) void k_tail_blend(const float* __restrict__ Z,
     const int n = min(*n_dev, n_max);
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
     if (node >= n) return;
-    float acc = 0.f;
-    const unsigned e0 = rowptr[node], e1 = rowptr[node + 1];
-    // Up to 64 edges at a time: lane l fetches edge l's source and offset (ONE coalesced load each instead of a
-    // dependent pair per edge) and works out that edge's 4 taps; the taps are then broadcast edge by edge, so the
-    // Z gathers of consecutive edges are independent loads in flight together.  Messages are still added in
-    // ascending edge order (= the reference's order inside a destination).
-    for (unsigned eb = e0; eb < e1; eb += 64) {
-        const int ne = min(64u, e1 - eb);
-        int s = 0, o00 = 0, o10 = 0, o01 = 0, o11 = 0;
-        float w00 = 0.f, w10 = 0.f, w01 = 0.f, w11 = 0.f;
-        if (c < ne) {
-            s = csr_src[eb + c];
-            const int pk = csr_dxy[eb + c];
-            const int dx = (int)(short)(pk & 0xffff), dy = pk >> 16;
-            // LUT grid attribute (spline_conv.py:27-30): d / (2*M*size) + 0.5
-            const float ax = __fadd_rn(__fdiv_rn((float)dx, div_x), 0.5f), ay = __fadd_rn(__fdiv_rn((float)dy, div_y), 0.5f);
-            int ix0, ix1, iy0, iy1; float bx0, bx1, by0, by1;
-            basis1(ax, &ix0, &ix1, &bx0, &bx1);
-            basis1(ay, &iy0, &iy1, &by0, &by1);
-            o00 = (ix0 + 5 * iy0) * 64; o10 = (ix1 + 5 * iy0) * 64; o01 = (ix0 + 5 * iy1) * 64; o11 = (ix1 + 5 * iy1) * 64;
-            w00 = __fmul_rn(bx0, by0); w10 = __fmul_rn(bx1, by0); w01 = __fmul_rn(bx0, by1); w11 = __fmul_rn(bx1, by1);
-        }
-        for (int j0 = 0; j0 < ne; j0 += 4) {                 // 4 edges = 16 independent gathers per trip
-            float z[4][4], ww[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = min(j0 + u, ne - 1);
-                const float* zr = Z + (size_t)__shfl(s, j, 64) * ldz + c;
-                z[u][0] = zr[__shfl(o00, j, 64)]; z[u][1] = zr[__shfl(o10, j, 64)];
-                z[u][2] = zr[__shfl(o01, j, 64)]; z[u][3] = zr[__shfl(o11, j, 64)];
-                ww[u][0] = __shfl(w00, j, 64); ww[u][1] = __shfl(w10, j, 64); ww[u][2] = __shfl(w01, j, 64); ww[u][3] = __shfl(w11, j, 64);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (j0 + u < ne) {
-                    float m = __fmul_rn(ww[u][0], z[u][0]);
-                    m = fmaf(ww[u][1], z[u][1], m);
-                    m = fmaf(ww[u][2], z[u][2], m);
-                    m = fmaf(ww[u][3], z[u][3], m);
-                    acc += m;
-                }
-            }
-        }
-    }
-    acc += Z[(size_t)node * ldz + root_col * 64 + c];
-    float y = fmaf(acc, scale[c], shift[c]);
-    if (Zs) y += fmaf(Zs[(size_t)node * ldzs + skip_col * 64 + c], sscale[c], sshift[c]);
-    y = fmaxf(y, 0.f);
+    const float y = evad_tail_blend_row(Z, ldz, root_col, Zs, ldzs, skip_col, rowptr, csr_src, csr_dxy, node, c, div_x, div_y,
+                                        scale, shift, sscale, sshift);
     out[(size_t)node * ldo + c] = y;
     for (int k = 64 + c; k < ld_pad_to; k += 64) out[(size_t)node * ldo + k] = 0.f;
 }

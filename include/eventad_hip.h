@@ -197,6 +197,23 @@ int eventad_tail_blend(const float* Z, int ldz, int root_col, const float* Zskip
                        const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,
                        const int32_t* n_dev, float div_x, float div_y, const float* bn_scale, const float* bn_shift,
                        const float* skip_scale, const float* skip_shift, float* out, int ldo, void* stream);
+/* eventad_tail_blend of a Layer's second convolution followed by eventad_pool_scatter of the next level (max: channels
+ * [y | 64 sampled map channels]; mean: bookkeeping only, the caller runs the mean gather through eventad_pool_scatter's
+ * path) in one launch: same arithmetic, same integer atomics, same results.  The slot tables (feat u32[S,128], sums, tsum,
+ * cnt, maxidx, bitmap) must be zero on entry; node_slot i32[n_max] receives each node's slot. */
+int eventad_tail_blend_pool(const float* Z, int ldz, int root_col, const float* Zskip, int ldzs, int skip_col,
+                            const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,
+                            const int32_t* n_dev, float div_x, float div_y, const float* bn_scale, const float* bn_shift,
+                            const float* skip_scale, const float* skip_shift, float* out, int ldo, const float* map_nhwc,
+                            int map_h, int map_w, const float* npos, const int32_t* npix, const int32_t* nbatch, int W,
+                            int H, float vsx, float vsy, int nx, int ny, int B, int mean_aggr, uint32_t* feat,
+                            uint64_t* sums, double* tsum, uint32_t* cnt, int32_t* maxidx, int32_t* node_slot,
+                            uint32_t* flags, uint32_t* bitmap, void* stream);
+/* The mean aggregation of eventad_pool_scatter (mean_aggr = 1) without its bookkeeping pass: feat f32[S, Ca+Cm] = sum of
+ * the member rows per slot, members added in ascending node order; node_slot as left by eventad_tail_blend_pool. */
+int eventad_pool_mean_gather(const float* xa, int lda, int Ca, const float* map_nhwc, int map_h, int map_w, int Cm,
+                             const float* npos, const int32_t* nbatch, const int32_t* node_slot, int n_max,
+                             const int32_t* n_dev, int W, int H, int nx, int ny, int B, float* feat, void* stream);
 /* NCHW -> NHWC of externally supplied CNN feature maps, up to 8 maps in one launch (LDS-tiled transposes).
  * desc = HOST array, 6 int64 per map: [0] in [1] out [2] B [3] C [4] H [5] W. */
 int eventad_nchw_to_nhwc_group(int n_maps, const int64_t* desc, void* stream);

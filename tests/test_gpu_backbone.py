@@ -275,3 +275,25 @@ def test_pooled_positions_at_full_density_and_non_power_of_two_width():
                     assert abs(q - round(q)) < Fraction(1, 1000), (j, d, float(q))
                     assert abs(round(float(got[j, d]) * size) - round(float(pos[j, d]) * size)) == 1
     print("pool1 nodes %d, positions off by one pixel at a rounding boundary: %d" % (n_l, len(bad)))
+
+
+@pytest.mark.parametrize("W,H,n,B,span", [(256, 256, 20000, 3, 50000), (640, 480, 20000, 2, 50000)])
+def test_fused_blend_and_pooling_equal_the_separate_launches(W, H, n, B, span):
+    """A pooled Layer's last blend that also scatters into the next level's voxel table (eventad_tail_blend_pool, + the mean
+    gather for pool4) leaves the same levels, bit for bit, as eventad_tail_blend followed by eventad_pool_scatter."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True, t_span_us=span))
+    sd = weights.random_graph_state()
+    dev = torch.device("cuda:0")
+    levels = []
+    for fused in (True, False):
+        nb = NativeBackbone(sd, W, H, dev)
+        nb.fused_blend_pool = fused
+        nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+        torch.cuda.synchronize()
+        assert nb.check_flags() & ~1 == 0
+        levels.append([(_level(L), L.y[: int(L.n_dev.item())].cpu(), L.csr_dxy[: int(L.e_dev.item())].cpu()) for L in nb._tail_view])
+    for (la, ya, da), (lb, yb, db) in zip(*levels):
+        assert la[0] == lb[0] and all(torch.equal(p, q) for p, q in zip(la[1:], lb[1:]))
+        assert torch.equal(ya, yb) and torch.equal(da, db)
