@@ -197,7 +197,7 @@ extern "C" int eventad_conv2d_nhwc(const float* in, const float* w, float* out, 
     const int bt = big ? 128 : 64;
     const long long tiles = ((Cout + bt - 1) / bt) * ((M + bt - 1) / bt);
     if (workspace && tiles < 160 && K >= 512) {
-        int ks = (int)(256 / tiles);
+        int ks = (int)(512 / tiles);
         if (ks > 8) ks = 8;
         while (ks > 1 && (K / ks < 128 || (long long)ks * MN > workspace_floats)) --ks;
         if (ks > 1) {
