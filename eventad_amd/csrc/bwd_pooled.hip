@@ -159,7 +159,8 @@ __device__ __forceinline__ float bp_member_value(const float* __restrict__ xa, i
     return v;
 }
 
-// pass 1 (max): smallest member index among the members that attain the pooled maximum, per (output node, channel)
+// pass 1 (max): smallest member index among the members that attain the pooled maximum, per (output node, channel), kept
+// as 0x7fffffff - index under atomicMax so that the table starts from zeros (cleared by a kernel: capturable)
 __global__ void k_pool_argmax(const float* __restrict__ xa, int lda, int Ca, const float* __restrict__ map, int map_h, int map_w, int Cm,
                               const float* __restrict__ npos, const int* __restrict__ nbatch, const int* __restrict__ node_slot,
                               const int* __restrict__ slot2node, int n_in, int W, int H, const float* __restrict__ xout, int ldo,
@@ -170,7 +171,7 @@ __global__ void k_pool_argmax(const float* __restrict__ xa, int lda, int Ca, con
     const int m = (int)(t / C), c = (int)(t % C);
     const int node = slot2node[node_slot[m]];
     const float v = bp_member_value(xa, lda, Ca, map, map_h, map_w, Cm, npos, nbatch, W, H, m, c);
-    if (v == xout[(size_t)node * ldo + c]) atomicMin(&argm[(size_t)node * C + c], m);
+    if (v == xout[(size_t)node * ldo + c]) atomicMax(&argm[(size_t)node * C + c], 0x7fffffff - m);
 }
 // pass 2: the gradient of (output node, channel) to that member (max), or to every member divided by the count (mean)
 __global__ void k_pool_route(const int* __restrict__ node_slot, const int* __restrict__ slot2node, const unsigned* __restrict__ cnt,
@@ -182,7 +183,7 @@ __global__ void k_pool_route(const int* __restrict__ node_slot, const int* __res
     const int m = (int)(t / C), c = (int)(t % C);
     const int slot = node_slot[m], node = slot2node[slot];
     const float g = dxout[(size_t)node * ldd + c];
-    const float v = mean ? g / (float)cnt[slot] : (argm[(size_t)node * C + c] == m ? g : 0.f);
+    const float v = mean ? g / (float)cnt[slot] : (argm[(size_t)node * C + c] == 0x7fffffff - m ? g : 0.f);
     if (c < Ca) dxa[(size_t)m * Ca + c] = v; else dsamp[(size_t)m * Cm + (c - Ca)] = v;
 }
 
@@ -198,7 +199,7 @@ extern "C" int eventad_pool_max_bwd(const float* xa, int lda, int Ca, const floa
     const int C = Ca + Cm;
     const unsigned blocks = evad_blocks((long long)n_in * C, 256);
     if (!mean) {
-        if (n_out > 0) hipMemsetAsync(argm, 0x7f, sizeof(int32_t) * (size_t)n_out * C, st);      // 0x7f7f7f7f: above every member index
+        evad_zero_async(argm, sizeof(int32_t) * (size_t)n_out * C, st);
         hipLaunchKernelGGL(k_pool_argmax, dim3(blocks), dim3(256), 0, st, xa, lda, Ca, map_nhwc, map_h, map_w, Cm, npos, nbatch,
                            node_slot, slot2node, n_in, W, H, xout, ldo, argm);
     }

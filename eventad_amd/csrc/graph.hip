@@ -884,6 +884,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // Rows are assembled in LDS and written as whole lines.  Batches whose timestamps are not monotone take an exact
 // per-event walk (the `continue` of the reference matters then).
 #define PIX_DEPTH 8
+#define PIX_CHUNK 32            // destination events of a pixel per round (a pixel rarely holds more)
 template <int GS, bool INT_CMP>
 __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int N, int W, int H,
                                              int steps, int Q, int dt_max, int x, int y, int plane_base, int i0, int md,
@@ -900,27 +901,41 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
     const int lo = ok ? max(st, en - Q) : en;                // the FIFO keeps only the newest Q ids
     const int len = en - lo, lenr = min(len, PIX_DEPTH), ninv = PIX_DEPTH - lenr;
     int eid[PIX_DEPTH], et[PIX_DEPTH];
+    // Padding (entries past the segment's length) counts as "not older" -- subtracted again through ninv -- and as out of
+    // the time window.  The asm statement keeps the padded values (two compares per entry and event below, instead of a
+    // mask per entry carried into the loop) and the two load sequences apart.
+#define PIX_ENTRY(V, C) { const int2 c_ = (C); eid[V] = (V) < lenr ? c_.x : 0x7fffffff; et[V] = (V) < lenr ? c_.y : -(1 << 30); \
+                          asm volatile("" : "+v"(eid[V]), "+v"(et[V])); }
+    // the PIX_DEPTH newest entries end at en - 1: one base address and constant offsets (reading into the neighbouring
+    // segment is harmless); only a wave that touches the first PIX_DEPTH events of the whole array clamps every index
+    if (__all(N >= PIX_DEPTH && (en >= PIX_DEPTH || !ok))) {
+        // (two entries per 16-byte load: the entries are 8-byte aligned, which is all a global load needs)
+        struct __attribute__((aligned(8))) Pair { int2 older, newer; };
+        const Pair* top = (const Pair*)(ev2 + (ok ? en - PIX_DEPTH : 0));
 #pragma unroll
-    for (int v = 0; v < PIX_DEPTH; ++v) {
-        const int2 c = ev2[min(max(en - 1 - v, lo), N - 1)];
-        eid[v] = v < lenr ? c.x : 0x7fffffff;                // padding counts as "not older" and is subtracted again (ninv)
-        et[v] = v < lenr ? c.y : -(1 << 30);                 // ... and as out of the time window
+        for (int v = 0; v < PIX_DEPTH; v += 2) {
+            const Pair pr = top[(PIX_DEPTH - 2 - v) / 2];
+            PIX_ENTRY(v, pr.newer) PIX_ENTRY(v + 1, pr.older)
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < PIX_DEPTH; ++v) PIX_ENTRY(v, ev2[min(max(en - 1 - v, lo), N - 1)])
     }
+#undef PIX_ENTRY
     // oldest entry of a deep pixel: if even that one is not older than the event, nothing below the registers is
     const int eold = len > PIX_DEPTH ? ev2[min(lo, N - 1)].x : 0x7fffffff;
-    unsigned long long todo = __ballot(my_cnt[lane] < MAXNB);            // bit d: event d still lacks sources
+    unsigned long long todo = __ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB);   // bit d: event d still lacks sources
     while (todo) {
-        int d;                                               // this group's event: the g-th lowest set bit (NG == 1: the lowest)
-        bool act = true;
-        if (NG == 1) { d = __ffsll((long long)todo) - 1; todo &= todo - 1; }
-        else {
-            unsigned long long t = todo;
-            for (int k = 0; k < g; ++k) t &= t - 1;
-            act = t != 0;
-            d = act ? __ffsll((long long)t) - 1 : 0;
+        int d = __ffsll((long long)todo) - 1;                // this group's event: the g-th lowest set bit, found on the scalar
+        todo &= todo - 1;                                    // unit for every group and then picked by the lane's group
 #pragma unroll
-            for (int k = 0; k < NG; ++k) todo &= todo - 1;   // (clearing a bit of 0 leaves 0)
+        for (int k = 1; k < NG; ++k) {
+            const int dk = __ffsll((long long)todo) - 1;     // -1 once no event is left (clearing a bit of 0 leaves 0)
+            todo &= todo - 1;
+            d = g == k ? dk : d;
         }
+        const bool act = d >= 0;
+        d = max(d, 0);
         const int base = my_cnt[d];
         const int2 mine = my_dest[d];
         const int me = mine.x, ts = mine.y;
@@ -928,13 +943,14 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
         // time window" for a prefix too (timestamps ascend with the ids here): two independent counts, and the sources are
         // the entries between the two prefixes.
         int cge = 0, nin = 0;
+        // (float)(ts - t) > (float)delta_t  <=>  ts - t > delta_t  <=>  t < ts - delta_t  whenever |delta_t| + 1 is exactly
+        // representable (timestamps are microseconds inside one clip: no overflow)
+        const int t_min = ts - dt_max;
 #pragma unroll
         for (int v = 0; v < PIX_DEPTH; ++v) {
-            const int dt = ts - et[v];
-            // (float)(ts - t) > (float)delta_t  <=>  ts - t > delta_t  whenever |delta_t| + 1 is exactly representable
-            const bool far = INT_CMP ? dt > dt_max : (float)dt > fdt;
-            cge += eid[v] < me ? 0 : 1;
-            nin += far ? 0 : 1;
+            cge += eid[v] >= me ? 1 : 0;
+            if (INT_CMP) nin += et[v] >= t_min ? 1 : 0;
+            else         nin += (float)(ts - et[v]) > fdt ? 0 : 1;
         }
         int nnew = cge - ninv;
         int nq = max(0, nin - nnew);
@@ -969,20 +985,20 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
 }
 
 template <int GS1, bool INT_CMP>
-__global__ __launch_bounds__(64) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
+__global__ __launch_bounds__(64, 7) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
                                                       const unsigned* __restrict__ flags_in, int N, int P, int W, int H, int steps,
                                                       int Q, int dt_max, int* __restrict__ ell_src,
                                                       uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
     constexpr int MAXNB = 16;
-    __shared__ int my_src[64 * MAXNB];
-    __shared__ unsigned short my_stp[64 * MAXNB];
-    __shared__ int2 my_dest[64];
-    __shared__ int my_cnt[64];
+    __shared__ int my_src[PIX_CHUNK * MAXNB];                // 3.4 KB per workgroup: LDS does not limit the waves per CU
+    __shared__ unsigned short my_stp[PIX_CHUNK * MAXNB];
+    __shared__ int2 my_dest[PIX_CHUNK];
+    __shared__ int my_cnt[PIX_CHUNK];
     const int lane = threadIdx.x;
-    const int p = blockIdx.x;
+    const int x = blockIdx.x, y = blockIdx.y, plane_base = (int)blockIdx.z * W * H;      // grid = (W, H, clips): no division
+    const int p = plane_base + x + W * y;
     const int ds = __builtin_amdgcn_readfirstlane((int)start[p]), de = __builtin_amdgcn_readfirstlane((int)start[p + 1]);
     if (de <= ds) return;
-    const int x = p % W, y = (p / W) % H, plane_base = p - x - W * y;
     if (flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE) {            // rare: plain per-event walk, rows written slot by slot
         for (int r = ds + lane; r < de; r += 64) {
             const int2 mine = ev2[r];
@@ -1010,28 +1026,28 @@ __global__ __launch_bounds__(64) void k_build_ell_pix(const int2* __restrict__ e
         }
         return;
     }
-    for (int d0 = ds; d0 < de; d0 += 64) {                   // the pixel's destination events, 64 at a time
-        const int md = min(64, de - d0);
-        my_dest[lane] = ev2[min(d0 + lane, N - 1)];
-        my_cnt[lane] = lane < md ? 1 : MAXNB;                // sources found so far for event d0 + lane (self edge first)
+    for (int d0 = ds; d0 < de; d0 += PIX_CHUNK) {            // the pixel's destination events, PIX_CHUNK at a time
+        const int md = min(PIX_CHUNK, de - d0);
+        if (lane < PIX_CHUNK) {
+            my_dest[lane] = ev2[min(d0 + lane, N - 1)];
+            my_cnt[lane] = lane < md ? 1 : MAXNB;            // sources found so far for event d0 + lane (self edge first)
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ((int4*)my_src)[j * 64 + lane] = make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ((uint4*)my_stp)[j * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
-        my_src[lane * MAXNB] = d0 + lane;
+        for (int j = 0; j < PIX_CHUNK / 16; ++j) ((int4*)my_src)[j * 64 + lane] = make_int4(0, 0, 0, 0);
+        if (lane < PIX_CHUNK * 2) ((uint4*)my_stp)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < PIX_CHUNK) my_src[lane * MAXNB] = d0 + lane;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int first = min(GS1, steps);
         ell_pix_pass<GS1, INT_CMP>(ev2, start, N, W, H, first, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt);
         for (int i0 = first; i0 < steps; i0 += 64) {
-            if (!__ballot(my_cnt[lane] < MAXNB)) break;
+            if (!__ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB)) break;
             ell_pix_pass<64, INT_CMP>(ev2, start, N, W, H, steps, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < PIX_CHUNK / 16; ++j)
             if (j * 64 + lane < md * 4) ((int4*)(ell_src + (size_t)d0 * MAXNB))[j * 64 + lane] = ((const int4*)my_src)[j * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j * 64 + lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[j * 64 + lane] = ((const uint4*)my_stp)[j * 64 + lane];
+        if (lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[lane] = ((const uint4*)my_stp)[lane];
         if (lane < md) deg[d0 + lane] = my_cnt[lane];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -1062,10 +1078,10 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
 #undef EVAD_RS
     } else if (fast && !bitmap && (variant == 2 || (variant == 0 && (double)N >= 2.0 * (double)B * W * H))) {
         const long long P = (long long)B * W * H;            // dense input (>= 2 events per pixel on average): wave per pixel
-        if (P > 0x7fffffffLL) return EVAD_ERR_ARG;
+        if (P > 0x7fffffffLL || H > 65535 || B > 65535) return EVAD_ERR_ARG;      // grid = (W, H, B)
         const bool int_cmp = delta_t_us > -(1 << 24) + 1 && delta_t_us < (1 << 24) - 1;
         const bool very_dense = (double)N >= 5.0 * (double)P;
-#define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC>), dim3((unsigned)P), dim3(64), 0, st, (const int2*)ev2, pix_start, \
+#define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC>), dim3((unsigned)W, (unsigned)H, (unsigned)B), dim3(64), 0, st, (const int2*)ev2, pix_start, \
                                             counters, N, (int)P, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg)
         if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
         else            { if (int_cmp) EVAD_PIX(32, true); else EVAD_PIX(32, false); }
