@@ -884,46 +884,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // Rows are assembled in LDS and written as whole lines.  Batches whose timestamps are not monotone take an exact
 // per-event walk (the `continue` of the reference matters then).
 #define PIX_DEPTH 8
-#define PIX_CHUNK 32            // destination events of a pixel per round (a pixel rarely holds more)
-template <int GS, bool INT_CMP>
+// LDS written by one lane and read by another lane of the same wave: the LDS unit executes one wave's instructions in
+// order, so only the compiler has to keep them in order.  (A wavefront-scope fence also waits for every outstanding
+// global load and store -- the rows just written, the bounds requested ahead for the next pixel.)
+#define PIX_LDS_ORDER() asm volatile("" ::: "memory")
+#define PIX_CHUNK 16            // destination events of a pixel per round (a pixel rarely holds more)
+// segment bounds of the neighbour pixel at offset (sdx, sdy) from (x, y); live = the lane's spiral step exists.  A pixel
+// outside the sensor (or a lane past the last step) gets an empty segment.
+struct __attribute__((aligned(4))) PixBounds { unsigned first, end; };
+__device__ __forceinline__ void pix_bounds(const unsigned* __restrict__ start, int x, int y, int plane_base, int W, int H, int sdx, int sdy,
+                                           bool live, int& st, int& en) {
+    const int xn = x + sdx, yn = y + sdy;
+    const bool ok = live && xn >= 0 && yn >= 0 && xn < W && yn < H;
+    const PixBounds se = *(const PixBounds*)(start + (ok ? plane_base + xn + W * yn : 0));      // one 8-byte load (4-byte aligned)
+    en = (int)se.end;
+    st = ok ? (int)se.first : en;
+}
+
+template <int GS, bool INT_CMP, bool PRE>
 __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int N, int W, int H,
                                              int steps, int Q, int dt_max, int x, int y, int plane_base, int i0, int md,
-                                             int* my_src, unsigned short* my_stp, const int2* my_dest, int* my_cnt) {
+                                             int* my_src, unsigned short* my_stp, const int2* my_dest, int* my_cnt, int st, int en) {
     constexpr int MAXNB = 16, NG = 64 / GS;
     const int lane = threadIdx.x & 63, g = lane / GS, l = lane % GS;
     const float fdt = (float)dt_max;
     const int i = i0 + l;
-    const int ii = min(i, steps - 1);
-    const int xn = x + c_spiral[2 * ii], yn = y + c_spiral[2 * ii + 1];
-    const bool ok = i < steps && xn >= 0 && yn >= 0 && xn < W && yn < H;
-    const int q = ok ? plane_base + xn + W * yn : 0;
-    const int st = (int)start[q], en = (int)start[q + 1];
-    const int lo = ok ? max(st, en - Q) : en;                // the FIFO keeps only the newest Q ids
+    if (!PRE) {                                              // (the first pass gets its bounds from the caller, loaded ahead)
+        const int ii = min(i, steps - 1);
+        pix_bounds(start, x, y, plane_base, W, H, c_spiral[2 * ii], c_spiral[2 * ii + 1], i < steps, st, en);
+    }
+    const int lo = max(st, en - Q);                          // the FIFO keeps only the newest Q ids
     const int len = en - lo, lenr = min(len, PIX_DEPTH), ninv = PIX_DEPTH - lenr;
+    // oldest entry of a deep pixel: if even that one is not older than the event, nothing below the registers is
+    const int eold = len > PIX_DEPTH ? ev2[min(lo, N - 1)].x : 0x7fffffff;
     int eid[PIX_DEPTH], et[PIX_DEPTH];
     // Padding (entries past the segment's length) counts as "not older" -- subtracted again through ninv -- and as out of
     // the time window.  The asm statement keeps the padded values (two compares per entry and event below, instead of a
     // mask per entry carried into the loop) and the two load sequences apart.
-#define PIX_ENTRY(V, C) { const int2 c_ = (C); eid[V] = (V) < lenr ? c_.x : 0x7fffffff; et[V] = (V) < lenr ? c_.y : -(1 << 30); \
-                          asm volatile("" : "+v"(eid[V]), "+v"(et[V])); }
-    // the PIX_DEPTH newest entries end at en - 1: one base address and constant offsets (reading into the neighbouring
-    // segment is harmless); only a wave that touches the first PIX_DEPTH events of the whole array clamps every index
-    if (__all(N >= PIX_DEPTH && (en >= PIX_DEPTH || !ok))) {
-        // (two entries per 16-byte load: the entries are 8-byte aligned, which is all a global load needs)
-        struct __attribute__((aligned(8))) Pair { int2 older, newer; };
-        const Pair* top = (const Pair*)(ev2 + (ok ? en - PIX_DEPTH : 0));
+#define PIX_ENTRY(V, CX, CY) { eid[V] = (V) < lenr ? (CX) : 0x7fffffff; et[V] = (V) < lenr ? (CY) : -(1 << 30); \
+                               asm volatile("" : "+v"(eid[V]), "+v"(et[V])); }
+    // the PIX_DEPTH newest entries end at en - 1: one base address, four 16-byte loads (entries are 8-byte aligned, which
+    // is all a global load needs; reading into the neighbouring segment where the pixel holds fewer is harmless); only a
+    // wave that touches the first PIX_DEPTH events of the whole array clamps every index
+    if (__all(N >= PIX_DEPTH && (en >= PIX_DEPTH || len == 0))) {
+        struct __attribute__((aligned(8))) Piece { int4 v; };
+        const Piece* top = (const Piece*)(ev2 + (len > 0 ? en - PIX_DEPTH : 0));
 #pragma unroll
-        for (int v = 0; v < PIX_DEPTH; v += 2) {
-            const Pair pr = top[(PIX_DEPTH - 2 - v) / 2];
-            PIX_ENTRY(v, pr.newer) PIX_ENTRY(v + 1, pr.older)
+        for (int c = 0; c < 4; ++c) {
+            const int4 r = top[c].v;                         // entries en - 8 + 2c (older) and en - 7 + 2c
+            PIX_ENTRY(PIX_DEPTH - 1 - 2 * c, r.x, r.y) PIX_ENTRY(PIX_DEPTH - 2 - 2 * c, r.z, r.w)
         }
     } else {
 #pragma unroll
-        for (int v = 0; v < PIX_DEPTH; ++v) PIX_ENTRY(v, ev2[min(max(en - 1 - v, lo), N - 1)])
+        for (int v = 0; v < PIX_DEPTH; ++v) { const int2 c = ev2[min(max(en - 1 - v, lo), N - 1)]; PIX_ENTRY(v, c.x, c.y) }
     }
 #undef PIX_ENTRY
-    // oldest entry of a deep pixel: if even that one is not older than the event, nothing below the registers is
-    const int eold = len > PIX_DEPTH ? ev2[min(lo, N - 1)].x : 0x7fffffff;
     unsigned long long todo = __ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB);   // bit d: event d still lacks sources
     while (todo) {
         int d = __ffsll((long long)todo) - 1;                // this group's event: the g-th lowest set bit, found on the scalar
@@ -955,13 +970,19 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
         int nnew = cge - ninv;
         int nq = max(0, nin - nnew);
         if (!act) nq = 0;
-        if (act && eold < me && nnew + nq == PIX_DEPTH) {                // deep pixel, registers undecided: read on
-            for (int s = en - 1 - PIX_DEPTH; s >= lo && nq < MAXNB; --s) {
-                const int2 c = ev2[s];
-                if (c.x >= me) { ++nnew; continue; }
-                const int dt = ts - c.y;
-                if (INT_CMP ? dt > dt_max : (float)dt > fdt) break;
-                ++nq;
+        if (act && eold < me && nnew + nq == PIX_DEPTH) {                // deep pixel, registers undecided: read on,
+            bool stop = false;                                           // four entries per round trip
+            for (int s = en - 1 - PIX_DEPTH; s >= lo && nq < MAXNB && !stop; s -= 4) {
+                int2 c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k] = ev2[max(s - k, lo)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (stop || s - k < lo || nq >= MAXNB) continue;
+                    if (c[k].x >= me) { ++nnew; continue; }
+                    const int dt = ts - c[k].y;
+                    if (INT_CMP ? dt > dt_max : (float)dt > fdt) stop = true; else ++nq;
+                }
             }
         }
         // inclusive sum of nq over the lanes of the group, lane order = spiral order: a shift-and-add scan inside each row of
@@ -981,75 +1002,100 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
         }
         if (l == GS - 1 && act) my_cnt[d] = min(MAXNB, base + inc);      // the group's last lane holds the total
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS written by one lane, read by others of the wave
+    PIX_LDS_ORDER();
 }
 
+// Workgroup = 4 waves on a strip of PIX_STRIP pixels of one sensor row: at any moment the four waves work on four adjacent
+// pixels, whose 7x7 (...) neighbourhoods are nearly the same cache lines, so most of a wave's gathers hit the CU's L1 (one
+// wave per workgroup, dealt pixel by pixel over all CUs, missed it on nearly every line and waited for L2).  Strips are
+// numbered so that each XCD (workgroup id mod 8) owns one contiguous eighth of them: its L2 then holds one band of rows.
+#define PIX_STRIP 16
 template <int GS1, bool INT_CMP>
-__global__ __launch_bounds__(64, 7) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
-                                                      const unsigned* __restrict__ flags_in, int N, int P, int W, int H, int steps,
+__global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
+                                                      const unsigned* __restrict__ flags_in, int N, int n_strips, int W, int H, int steps,
                                                       int Q, int dt_max, int* __restrict__ ell_src,
                                                       uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
     constexpr int MAXNB = 16;
-    __shared__ int my_src[PIX_CHUNK * MAXNB];                // 3.4 KB per workgroup: LDS does not limit the waves per CU
-    __shared__ unsigned short my_stp[PIX_CHUNK * MAXNB];
-    __shared__ int2 my_dest[PIX_CHUNK];
-    __shared__ int my_cnt[PIX_CHUNK];
-    const int lane = threadIdx.x;
-    const int x = blockIdx.x, y = blockIdx.y, plane_base = (int)blockIdx.z * W * H;      // grid = (W, H, clips): no division
-    const int p = plane_base + x + W * y;
-    const int ds = __builtin_amdgcn_readfirstlane((int)start[p]), de = __builtin_amdgcn_readfirstlane((int)start[p + 1]);
-    if (de <= ds) return;
-    if (flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE) {            // rare: plain per-event walk, rows written slot by slot
-        for (int r = ds + lane; r < de; r += 64) {
-            const int2 mine = ev2[r];
-            int* row = ell_src + (size_t)r * MAXNB;
-            uint16_t* srow = ell_step + (size_t)r * MAXNB;
-            for (int e = 1; e < MAXNB; ++e) { row[e] = 0; srow[e] = 0; }
-            row[0] = r; srow[0] = 0;
-            int nn = 1;
-            for (int i = 0; i < steps && nn < MAXNB; ++i) {
-                const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
-                if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
-                const int q = plane_base + xn + W * yn;
-                const int st = (int)start[q], en = (int)start[q + 1];
-                const int lo = max(st, en - Q);
-                for (int s = en - 1; s >= lo; --s) {
-                    const int2 c = ev2[s];
-                    if (mine.x > c.x) {
-                        if ((float)(mine.y - c.y) > (float)dt_max) continue;
-                        row[nn] = s; srow[nn] = (uint16_t)i;
-                        if (++nn >= MAXNB) break;
+    static_assert(PIX_CHUNK == 16, "one int4 per lane covers the chunk's rows");
+    __shared__ int s_src[4][PIX_CHUNK * MAXNB];
+    __shared__ unsigned short s_stp[4][PIX_CHUNK * MAXNB];
+    __shared__ int2 s_dest[4][PIX_CHUNK];
+    __shared__ int s_cnt[4][PIX_CHUNK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int* my_src = s_src[wv]; unsigned short* my_stp = s_stp[wv]; int2* my_dest = s_dest[wv]; int* my_cnt = s_cnt[wv];
+    const int per_xcd = (n_strips + 7) >> 3;
+    const int strip = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (strip >= n_strips) return;                           // (no workgroup barrier below: the waves are independent)
+    const int strips_x = (W + PIX_STRIP - 1) / PIX_STRIP;
+    const int row = strip / strips_x, y = row % H, plane_base = (row / H) * W * H, x0 = (strip % strips_x) * PIX_STRIP;
+    const bool walk = (flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE) != 0;
+    // A wave's time goes into waiting for dependent loads (own segment -> neighbour bounds -> entries), not into arithmetic:
+    // the first pass's spiral offsets are the same for every pixel and are read once, and the bounds a pixel needs first
+    // (its own segment, its neighbours') are requested one pixel ahead.
+    const int first = min(GS1, steps), l1 = lane % GS1, ii1 = min(l1, steps - 1);
+    const int sdx = c_spiral[2 * ii1], sdy = c_spiral[2 * ii1 + 1];
+    const int xend = min(x0 + PIX_STRIP, W);
+    int x = x0 + wv;
+    if (x >= xend) return;
+    int st_n, en_n;                                          // neighbour bounds and own segment of the wave's next pixel, in flight
+    pix_bounds(start, x, y, plane_base, W, H, sdx, sdy, l1 < first, st_n, en_n);
+    PixBounds own_n = *(const PixBounds*)(start + plane_base + x + W * y);
+    for (; x < xend; x += 4) {
+        const int st1 = st_n, en1 = en_n;
+        const int ds = __builtin_amdgcn_readfirstlane((int)own_n.first), de = __builtin_amdgcn_readfirstlane((int)own_n.end);
+        if (x + 4 < xend) {
+            pix_bounds(start, x + 4, y, plane_base, W, H, sdx, sdy, l1 < first, st_n, en_n);
+            own_n = *(const PixBounds*)(start + plane_base + x + 4 + W * y);
+        }
+        if (de <= ds) continue;
+        if (walk) {                                          // rare: plain per-event walk, rows written slot by slot
+            for (int r = ds + lane; r < de; r += 64) {
+                const int2 mine = ev2[r];
+                int* orow = ell_src + (size_t)r * MAXNB;
+                uint16_t* srow = ell_step + (size_t)r * MAXNB;
+                for (int e = 1; e < MAXNB; ++e) { orow[e] = 0; srow[e] = 0; }
+                orow[0] = r; srow[0] = 0;
+                int nn = 1;
+                for (int i = 0; i < steps && nn < MAXNB; ++i) {
+                    const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+                    if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
+                    const int q = plane_base + xn + W * yn;
+                    const int st = (int)start[q], en = (int)start[q + 1];
+                    const int lo = max(st, en - Q);
+                    for (int s = en - 1; s >= lo; --s) {
+                        const int2 c = ev2[s];
+                        if (mine.x > c.x) {
+                            if ((float)(mine.y - c.y) > (float)dt_max) continue;
+                            orow[nn] = s; srow[nn] = (uint16_t)i;
+                            if (++nn >= MAXNB) break;
+                        }
                     }
                 }
+                deg[r] = nn;
             }
-            deg[r] = nn;
+            continue;
         }
-        return;
-    }
-    for (int d0 = ds; d0 < de; d0 += PIX_CHUNK) {            // the pixel's destination events, PIX_CHUNK at a time
-        const int md = min(PIX_CHUNK, de - d0);
-        if (lane < PIX_CHUNK) {
-            my_dest[lane] = ev2[min(d0 + lane, N - 1)];
-            my_cnt[lane] = lane < md ? 1 : MAXNB;            // sources found so far for event d0 + lane (self edge first)
+        for (int d0 = ds; d0 < de; d0 += PIX_CHUNK) {        // the pixel's destination events, PIX_CHUNK at a time
+            const int md = min(PIX_CHUNK, de - d0);
+            if (lane < PIX_CHUNK) {
+                my_dest[lane] = ev2[min(d0 + lane, N - 1)];
+                my_cnt[lane] = lane < md ? 1 : MAXNB;        // sources found so far for event d0 + lane (self edge first)
+            }
+            ((int4*)my_src)[lane] = make_int4(0, 0, 0, 0);   // PIX_CHUNK * 16 ints = 64 int4
+            if (lane < PIX_CHUNK * 2) ((uint4*)my_stp)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            PIX_LDS_ORDER();
+            if (lane < PIX_CHUNK) my_src[lane * MAXNB] = d0 + lane;
+            PIX_LDS_ORDER();
+            ell_pix_pass<GS1, INT_CMP, true>(ev2, start, N, W, H, first, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt, st1, en1);
+            for (int i0 = first; i0 < steps; i0 += 64) {
+                if (!__ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB)) break;
+                ell_pix_pass<64, INT_CMP, false>(ev2, start, N, W, H, steps, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt, 0, 0);
+            }
+            if (lane < md * 4) ((int4*)(ell_src + (size_t)d0 * MAXNB))[lane] = ((const int4*)my_src)[lane];
+            if (lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[lane] = ((const uint4*)my_stp)[lane];
+            if (lane < md) deg[d0 + lane] = my_cnt[lane];
+            PIX_LDS_ORDER();
         }
-#pragma unroll
-        for (int j = 0; j < PIX_CHUNK / 16; ++j) ((int4*)my_src)[j * 64 + lane] = make_int4(0, 0, 0, 0);
-        if (lane < PIX_CHUNK * 2) ((uint4*)my_stp)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < PIX_CHUNK) my_src[lane * MAXNB] = d0 + lane;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int first = min(GS1, steps);
-        ell_pix_pass<GS1, INT_CMP>(ev2, start, N, W, H, first, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt);
-        for (int i0 = first; i0 < steps; i0 += 64) {
-            if (!__ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB)) break;
-            ell_pix_pass<64, INT_CMP>(ev2, start, N, W, H, steps, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt);
-        }
-#pragma unroll
-        for (int j = 0; j < PIX_CHUNK / 16; ++j)
-            if (j * 64 + lane < md * 4) ((int4*)(ell_src + (size_t)d0 * MAXNB))[j * 64 + lane] = ((const int4*)my_src)[j * 64 + lane];
-        if (lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[lane] = ((const uint4*)my_stp)[lane];
-        if (lane < md) deg[d0 + lane] = my_cnt[lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
@@ -1078,13 +1124,18 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
 #undef EVAD_RS
     } else if (fast && !bitmap && (variant == 2 || (variant == 0 && (double)N >= 2.0 * (double)B * W * H))) {
         const long long P = (long long)B * W * H;            // dense input (>= 2 events per pixel on average): wave per pixel
-        if (P > 0x7fffffffLL || H > 65535 || B > 65535) return EVAD_ERR_ARG;      // grid = (W, H, B)
+        const long long strips = (long long)B * H * ((W + PIX_STRIP - 1) / PIX_STRIP);
+        if (P > 0x7fffffffLL || strips > 0x7ffffff0LL) return EVAD_ERR_ARG;
+        const int n_strips = (int)strips, wgs = (n_strips + 7) / 8 * 8;        // every XCD the same number of workgroups
         const bool int_cmp = delta_t_us > -(1 << 24) + 1 && delta_t_us < (1 << 24) - 1;
         const bool very_dense = (double)N >= 5.0 * (double)P;
-#define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC>), dim3((unsigned)W, (unsigned)H, (unsigned)B), dim3(64), 0, st, (const int2*)ev2, pix_start, \
-                                            counters, N, (int)P, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg)
-        if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
-        else            { if (int_cmp) EVAD_PIX(32, true); else EVAD_PIX(32, false); }
+#define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, \
+                                            counters, N, n_strips, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg)
+        // radius <= 3: all 49 steps in one 64-lane pass, one event at a time (a second pass costs a pixel three dependent
+        // round trips, an event more in the loop a few hundred cycles)
+        if (steps <= 64)     { if (int_cmp) EVAD_PIX(64, true); else EVAD_PIX(64, false); }
+        else if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
+        else                 { if (int_cmp) EVAD_PIX(32, true); else EVAD_PIX(32, false); }
 #undef EVAD_PIX
     } else if (fast) {
         const bool by_rank = (double)N >= 2.0 * (double)B * W * H;          // (variant 3 keeps this walk for dense input)
