@@ -869,8 +869,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // Pixel-centric edge search for dense input (several events per pixel: C3, C5).
 // All events of one pixel walk the SAME neighbour pixels in the same order; they differ only in their own id and time.
 // The per-event walks above load every neighbour pixel's bounds and FIFO entries once per destination EVENT, one
-// dependent round trip at a time, and a wave waits for the longest walk of its 64 lanes.  Here one wave (= one
-// workgroup) owns one destination PIXEL.  A pass covers GS consecutive spiral steps: lane l of each of the 64/GS lane
+// dependent round trip at a time, and a wave waits for the longest walk of its 64 lanes.  Here one wave owns one
+// destination PIXEL at a time.  A pass covers GS consecutive spiral steps: lane l of each of the 64/GS lane
 // groups holds, in registers, the bounds and the PIX_DEPTH newest FIFO entries of step i0 + l (two round trips per
 // pass), and the groups then go through the pixel's unfinished events, 64/GS at a time, one event per group.  For its
 // event a lane counts, among its entries, those not older than the event (ids ascend inside a segment, so they are the
@@ -878,9 +878,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // decrease with the id they are the next `nq`); the exclusive sum of nq over the lower lanes of the group -- spiral
 // order -- is where the lane's sources go in the row, newest first, until 16 slots are taken: the reference's row.
 // A lane whose registers do not decide a deep pixel (all PIX_DEPTH entries newer or taken) reads on from memory.
-// The first pass runs with 64/GS1 groups of GS1 steps (16 at five or more events per pixel, else 32: most events are
-// done after that many pixels); the events that still have fewer than 16 sources -- the early ones of the clip -- go on
-// alone with 64 steps per pass.
+// The first pass takes the whole spiral when it has at most 64 steps (radius <= 3; one event at a time), else it runs
+// with 64/GS1 groups of GS1 steps (16 at five or more events per pixel, else 32: most events are done after that many
+// pixels) and the events that still have fewer than 16 sources -- the early ones of the clip -- go on alone with 64
+// steps per pass.
 // Rows are assembled in LDS and written as whole lines.  Batches whose timestamps are not monotone take an exact
 // per-event walk (the `continue` of the reference matters then).
 #define PIX_DEPTH 8
@@ -923,15 +924,17 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
     // mask per entry carried into the loop) and the two load sequences apart.
 #define PIX_ENTRY(V, CX, CY) { eid[V] = (V) < lenr ? (CX) : 0x7fffffff; et[V] = (V) < lenr ? (CY) : -(1 << 30); \
                                asm volatile("" : "+v"(eid[V]), "+v"(et[V])); }
-    // the PIX_DEPTH newest entries end at en - 1: one base address, four 16-byte loads (entries are 8-byte aligned, which
-    // is all a global load needs; reading into the neighbouring segment where the pixel holds fewer is harmless); only a
-    // wave that touches the first PIX_DEPTH events of the whole array clamps every index
+    // The PIX_DEPTH newest entries end at en - 1: one base address, 16-byte loads of two entries each (entries are 8-byte
+    // aligned, which is all a global load needs; an odd length reads one entry of the neighbouring segment, harmless).  A
+    // lane only asks for the pairs its segment has.  Only a wave that touches the first PIX_DEPTH events of the whole array
+    // clamps every index instead.
     if (__all(N >= PIX_DEPTH && (en >= PIX_DEPTH || len == 0))) {
         struct __attribute__((aligned(8))) Piece { int4 v; };
         const Piece* top = (const Piece*)(ev2 + (len > 0 ? en - PIX_DEPTH : 0));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int4 r = top[c].v;                         // entries en - 8 + 2c (older) and en - 7 + 2c
+        for (int c = 3; c >= 0; --c) {
+            int4 r = make_int4(0, 0, 0, 0);
+            if (lenr > 2 * (3 - c)) r = top[c].v;            // entries en - 8 + 2c (older) and en - 7 + 2c
             PIX_ENTRY(PIX_DEPTH - 1 - 2 * c, r.x, r.y) PIX_ENTRY(PIX_DEPTH - 2 - 2 * c, r.z, r.w)
         }
     } else {
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict
     __shared__ unsigned short s_stp[4][PIX_CHUNK * MAXNB];
     __shared__ int2 s_dest[4][PIX_CHUNK];
     __shared__ int s_cnt[4][PIX_CHUNK];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform: a pixel's own bounds are a scalar load)
     int* my_src = s_src[wv]; unsigned short* my_stp = s_stp[wv]; int2* my_dest = s_dest[wv]; int* my_cnt = s_cnt[wv];
     const int per_xcd = (n_strips + 7) >> 3;
     const int strip = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
