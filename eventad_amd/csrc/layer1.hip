@@ -250,6 +250,7 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
                      int max_nb, hipStream_t st) {
     constexpr int LS = CINP * 16;
     if (max_nb != 16) return EVAD_ERR_ARG;              // an ELL row is read as 4 x int4 + 4 x uint2
+    if ((unsigned long long)N * 80ull > 0xffffffffull) return EVAD_ERR_ARG;     // 32-bit byte offsets into the row arrays (53 M events)
     const size_t fixed = sizeof(float) * (SKIP ? 320 : 0), budget = 80 * 1024;   // two workgroups per CU (160 KiB LDS)
     int nlds = (int)((budget - fixed) / (sizeof(float) * LS)) - 2;               // spiral steps whose matrices fit beside the 2 special ones
     if (nlds > steps) nlds = steps;

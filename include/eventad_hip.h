@@ -123,7 +123,8 @@ int eventad_ell_to_edges(const int32_t* ell_src, const int32_t* deg, const int32
  * lin.mlp.weight^T [20][16] times the skip BatchNorm's scale.  The input-channel rows of every matrix are stored in the
  * order [i][j] (row i*4 + j = channel 4j+i for i < 4, channel 16+j for i = 4): the 4 lanes of a destination split the
  * input channels.  work u32[256]: per-XCD work counters, one per 128-byte line, ZERO on entry (the waves pull groups of
- * 64 destinations from them), left non-zero; each call needs its own zeroed 256 words.  max_num_neighbors must be 16. */
+ * 64 destinations from them), left non-zero; each call needs its own zeroed 256 words.  max_num_neighbors must be 16;
+ * N <= 53,687,091 (32-bit byte offsets into the 80-byte rows), else EVAD_ERR_ARG. */
 int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
                      const float* lut, const float* shift, float* y1, uint32_t* work, int N, int steps,
                      int max_num_neighbors, void* stream);
