@@ -1125,8 +1125,9 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         if (radius_px == 1) { if (bitmap) EVAD_RS(1, true); else EVAD_RS(1, false); }
         else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
 #undef EVAD_RS
-    } else if (fast && !bitmap && (variant == 2 || (variant == 0 && (double)N >= 2.0 * (double)B * W * H))) {
-        const long long P = (long long)B * W * H;            // dense input (>= 2 events per pixel on average): wave per pixel
+    } else if (fast && !bitmap && (variant == 2 || (variant == 0 && (double)N >= 0.4 * (double)B * W * H))) {
+        // (measured crossover against the per-event walk: 0.3-0.4 events per pixel at radius 13, below 1.4 at radius 3)
+        const long long P = (long long)B * W * H;            // wave per pixel
         const long long strips = (long long)B * H * ((W + PIX_STRIP - 1) / PIX_STRIP);
         if (P > 0x7fffffffLL || strips > 0x7ffffff0LL) return EVAD_ERR_ARG;
         const int n_strips = (int)strips, wgs = (n_strips + 7) / 8 * 8;        // every XCD the same number of workgroups
@@ -1136,7 +1137,7 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
                                             counters, N, n_strips, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg)
         // radius <= 3: all 49 steps in one 64-lane pass, one event at a time (a second pass costs a pixel three dependent
         // round trips, an event more in the loop a few hundred cycles)
-        if (steps <= 64)     { if (int_cmp) EVAD_PIX(64, true); else EVAD_PIX(64, false); }
+        if (steps <= 64 || (double)N < 2.0 * (double)P) { if (int_cmp) EVAD_PIX(64, true); else EVAD_PIX(64, false); }      // (... or few events per pixel)
         else if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
         else                 { if (int_cmp) EVAD_PIX(32, true); else EVAD_PIX(32, false); }
 #undef EVAD_PIX

@@ -98,7 +98,7 @@ int eventad_sort_events_static(const float* pos, const int64_t* batch, const flo
  * LUT cell of the source pixel), deg i32[N].  bitmap (nullable): also set, for every edge,
  * the source-voxel bit in the destination voxel's pool1 neighbour bitmap u32[S,3] (= eventad_pool_edges_mark_ell).
  * variant (needs ev2 and max_num_neighbors == 16, else the reference-style walk runs and bitmap must be NULL):
- * 0 = by density: with two or more events per pixel on average and no bitmap, one wave per destination PIXEL (lanes =
+ * 0 = by density: from 0.4 events per pixel on average and no bitmap, one wave per destination PIXEL at a time (lanes =
  * spiral steps, the neighbour pixels' newest entries held in registers and shared by all events of the pixel);
  * otherwise thread per event walking the spiral with the row in registers and an early exit after 16 neighbours;
  * 1 = row scan, radius 1 or 3 only (2R+1 contiguous range look-ups per event instead of (2R+1)^2 pixel
