@@ -325,6 +325,46 @@ extern "C" int eventad_format_events(const int16_t* pos, const int32_t* t, const
     return evad_last_error();
 }
 
+// Up to EVAD_COPY_MAX device-to-device copies in ONE launch: the fields of the next batch into the static input buffers a
+// captured step reads (a batch is ~10 tensors; ten copy launches in front of the backbone graph cost more stream time
+// than the 10 MB they move).  blockIdx.y = segment; 16-byte vectors where both ends are 16-byte aligned, bytes else.
+#define EVAD_COPY_MAX 16
+struct CopyGroup { const char* src[EVAD_COPY_MAX]; char* dst[EVAD_COPY_MAX]; unsigned long long bytes[EVAD_COPY_MAX]; };
+__global__ __launch_bounds__(256) void k_copy_group(CopyGroup g) {
+    const char* __restrict__ src = g.src[blockIdx.y];
+    char* __restrict__ dst = g.dst[blockIdx.y];
+    const unsigned long long bytes = g.bytes[blockIdx.y];
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long done = 0;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const unsigned long long nv = bytes >> 4;
+        for (unsigned long long i = tid; i < nv; i += nthr) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+        done = nv << 4;
+    }
+    for (unsigned long long i = done + tid; i < bytes; i += nthr) dst[i] = src[i];
+}
+
+extern "C" int eventad_copy_group(int n, const void* const* src, void* const* dst, const uint64_t* bytes, void* stream) {
+    if (n < 0 || n > EVAD_COPY_MAX || (n > 0 && (!src || !dst || !bytes))) return EVAD_ERR_ARG;
+    CopyGroup g;
+    unsigned long long most = 0;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] == 0) continue;
+        if (!src[i] || !dst[i]) return EVAD_ERR_ARG;
+        g.src[m] = (const char*)src[i]; g.dst[m] = (char*)dst[i]; g.bytes[m] = bytes[i];
+        if (bytes[i] > most) most = bytes[i];
+        ++m;
+    }
+    if (m == 0) return EVAD_OK;
+    for (int i = m; i < EVAD_COPY_MAX; ++i) { g.src[i] = nullptr; g.dst[i] = nullptr; g.bytes[i] = 0; }
+    unsigned long long blocks = (most / 16 + 255) / 256;     // one 16-byte vector per thread of the largest segment ...
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;                        // ... up to a grid-stride loop
+    hipLaunchKernelGGL(k_copy_group, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}
+
 // =============================================================================================
 // (B) native path: counting sort by pixel + ELL edge search
 // =============================================================================================

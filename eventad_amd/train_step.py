@@ -18,6 +18,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from ._lib import call
 from .ddp import GradSync
 
 
@@ -323,8 +324,33 @@ class TrainStep:
         return d["gb"], d["gh"]
 
     @staticmethod
-    def load_into(in_b, batch):
-        """Copy a batch into static (captured) input buffers of the same shapes, on the current stream."""
+    def _copy_pairs(pairs):
+        """[(dst, src)] of equal shapes, on the current stream: every pair of contiguous same-dtype tensors on this device goes
+        into ONE launch (eventad_copy_group, 16 per call) -- a batch is ~10 fields, and ten copy launches in front of the
+        backbone graph hold the chain's stream longer than the data they move; anything else (host memory, a dtype change)
+        takes torch's copy."""
+        import ctypes
+        fast = []
+        for dst, src in pairs:
+            if (src.is_cuda and dst.is_cuda and src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous()
+                    and dst.is_contiguous()):
+                if dst.numel():
+                    fast.append((dst, src))
+            else:
+                dst.copy_(src, non_blocking=True)
+        st = torch.cuda.current_stream().cuda_stream
+        for i in range(0, len(fast), 16):
+            part = fast[i: i + 16]
+            n = len(part)
+            srcs = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in part])
+            dsts = (ctypes.c_void_p * n)(*[d_.data_ptr() for d_, _ in part])
+            sizes = (ctypes.c_uint64 * n)(*[d_.numel() * d_.element_size() for d_, _ in part])
+            call("eventad_copy_group", n, ctypes.cast(srcs, ctypes.c_void_p), ctypes.cast(dsts, ctypes.c_void_p),
+                 ctypes.cast(sizes, ctypes.c_void_p), st)
+
+    @staticmethod
+    def _load_pairs(in_b, batch):
+        pairs = []
         for k in ("pos", "x", "batch", "image", "bbox", "bbox_batch", "bbox0", "bbox0_batch"):
             src, dst = getattr(batch, k, None), getattr(in_b, k, None)
             if dst is None:
@@ -332,10 +358,15 @@ class TrainStep:
             if src is None or src.shape != dst.shape:
                 raise ValueError("replay_dual: batch field %r has shape %s, the captured graphs need %s (one capture per shape bucket)"
                                  % (k, None if src is None else tuple(src.shape), tuple(dst.shape)))
-            dst.copy_(src, non_blocking=True)
+            pairs.append((dst, src))
         if getattr(in_b, "image_feats", None) is not None:
-            for dst, src in zip(in_b.image_feats, batch.image_feats):
-                dst.copy_(src, non_blocking=True)
+            pairs.extend(zip(in_b.image_feats, batch.image_feats))
+        return pairs
+
+    @classmethod
+    def load_into(cls, in_b, batch):
+        """Copy a batch into static (captured) input buffers of the same shapes, on the current stream."""
+        cls._copy_pairs(cls._load_pairs(in_b, batch))
 
     def _issue_backbone(self, d, c, next_batch, sg):
         """Backbone-stream part of a step: load the next batch into chain c's buffers (if given; None = chain c runs the
@@ -343,8 +374,12 @@ class TrainStep:
         with torch.cuda.stream(sg):
             sg.wait_event(d["ev_h"][c])                        # the last reader of feats[c] / in_h[c] is done
             if next_batch is not None:
-                self.load_into(d["in_b"][c], next_batch)
+                # the head's copy of the boxes comes from the same batch in the same launch
+                pairs = self._load_pairs(d["in_b"][c], next_batch)
+                pairs += [(d["in_h"][c].bbox, next_batch.bbox), (d["in_h"][c].bbox_batch, next_batch.bbox_batch)]
+                self._copy_pairs(pairs)
                 d["in_b_id"][c] += 1
+                d["in_h_id"][c] = d["in_b_id"][c]
             if d["in_h_id"][c] != d["in_b_id"][c]:
                 d["in_h"][c].copy_from(d["in_b"][c])
                 d["in_h_id"][c] = d["in_b_id"][c]

@@ -55,6 +55,12 @@ int eventad_spiral_offsets(int radius, int16_t* dxdy);
 int eventad_format_events(const int16_t* pos, const int32_t* t, const int8_t* x, int N, const int64_t* width,
                           const int64_t* height, const int64_t* time_window, float* pos_out, float* x_out, void* stream);
 
+/* Loading the next batch into the static input buffers of a captured step (the reference's loop hands each batch to the
+ * model as fresh tensors, utils/train.py:120-131; a hipGraph reads fixed addresses instead): n <= 16 device-to-device
+ * copies src[i] -> dst[i] of bytes[i] bytes in ONE launch.  src / dst / bytes are HOST arrays (read before the call
+ * returns); segments must not overlap each other's destinations. */
+int eventad_copy_group(int n, const void* const* src, void* const* dst, const uint64_t* bytes, void* stream);
+
 /* ---- (B) native graph build: replaces EV_TGN.forward + SlidingWindowGraph.forward ------------- */
 /* (ev_tgn.py:39-58, ev_graph.py:62-103, graph/utils.py:6-23) for one fresh batch.
  * eventad_sort_events: denormalise (ev_tgn.py:11-16), counting-sort the events by pixel, and emit

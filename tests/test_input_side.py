@@ -72,3 +72,34 @@ def test_hip_format_data_equals_torch_format_data():
     assert got.pos.dtype == torch.float32 and got.t is None
     assert torch.equal(got.pos.cpu(), want.pos) and torch.equal(got.x.cpu(), want.x)
     assert torch.allclose(got.image.cpu(), want.image, atol=1e-7, rtol=0)          # image / 255 stays a torch op on either device
+
+
+@pytest.mark.gpu
+def test_grouped_copy_moves_every_segment_exactly():
+    """eventad_copy_group: several device-to-device copies in one launch -- aligned and unaligned ends, sizes that are not
+    multiples of 16 bytes, an empty segment; bytes around every destination stay untouched."""
+    import ctypes
+    from eventad_amd._lib import call
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    sizes = [4_800_000, 1_600_004, 37, 0, 16, 3_200_001, 5]
+    offs = [0, 16, 3, 0, 8, 1, 7]                             # byte offsets of source and destination inside their buffers
+    srcs, dsts, want = [], [], []
+    for i, (n, o) in enumerate(zip(sizes, offs)):
+        a = torch.randint(0, 256, (n + 64,), dtype=torch.uint8, generator=g).to(dev)
+        b = torch.randint(0, 256, (n + 64,), dtype=torch.uint8, generator=g).to(dev)
+        w = b.clone()
+        q = o + (5 if i % 2 else 0)                           # even segments: both ends equally aligned (16-byte path at o = 0, 16)
+        w[q: q + n] = a[o: o + n]
+        srcs.append(a[o: o + n]); dsts.append(b[q: q + n]); want.append((b, w))
+    k = len(sizes)
+    sp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
+    dp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dsts])
+    nb = (ctypes.c_uint64 * k)(*sizes)
+    call("eventad_copy_group", k, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p),
+         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for b, w in want:
+        assert torch.equal(b, w)
+    with pytest.raises(Exception):
+        call("eventad_copy_group", 17, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p), 0)
