@@ -1,6 +1,6 @@
 """bench.py -- EventAD hot path on MI355X: clips/sec of one optimisation step (forward of the frozen
 DAGR backbone + ROI pooling + head forward/backward + grad-clip + AdamW, = reference
-utils/train.py:100-152) on the synthetic ROL-shaped configuration BASELINE.json's metric is quoted on
+utils/train.py:100-152) on the synthetic ROL-shaped configuration the headline metric is quoted on
 (C2: 256x256, 50k events/clip, precomputed CNN features, 8 clips per GPU).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
@@ -67,7 +67,7 @@ def build_model(W, H, B, dev, seed=42, live_cnn=False):
 
 
 def algorithmic_bytes(N, E, B, W, H):
-    """SURVEY.md 8(d) per-stage algorithmic bytes, keyed by the C-ABI call that implements the stage."""
+    """Per-stage algorithmic bytes (what the stage must read and write once), keyed by the C-ABI call that implements the stage."""
     maps1 = 4 * 64 * B * (H // 4) * (W // 4)
     return {
         "eventad_build_ell#1": 16 * N + 8 * E,                                   # S1

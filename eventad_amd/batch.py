@@ -1,5 +1,5 @@
 """Minimal batch container that duck-types the torch_geometric `Batch` attributes the
-EventAD hot path reads (SURVEY.md 8b: x, pos, t, batch, image, bbox, bbox_batch, bbox0,
+EventAD hot path reads (x, pos, t, batch, image, bbox, bbox_batch, bbox0,
 bbox0_batch, width, height, time_window, num_graphs, sequence; input schema of
 src/dagr/data/utils.py:6-19 + PyG collate with follow_batch=['bbox','bbox0'])."""
 import torch

@@ -80,7 +80,7 @@ def _ev_graph_module():
     return m
 
 
-# the test/validation loop (SURVEY 8f-1): only these two modules of the reference's `utils` package are replaced --
+# the test/validation loop: only these two modules of the reference's `utils` package are replaced --
 # the package itself (data loaders, result files, ...) stays the reference's, so they are registered as submodules
 _EVAL_ALIASES = {"utils.test": "eventad_amd.utils.test", "utils.evaluation": "eventad_amd.utils.evaluation"}
 

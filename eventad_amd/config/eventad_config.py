@@ -1,7 +1,7 @@
 """Mirror of `config.eventad_config` (reference config/eventad_config.py:5-134): same flags and
 defaults, same YAML merge rule (a YAML key fills an attribute only when the flag is absent).
 The default --config points at the dagr-s-dsec.yaml shipped next to this file, because the
-reference tree does not contain the YAML its default names (SURVEY.md fact 4)."""
+reference tree does not contain the YAML its default names."""
 import argparse
 from pathlib import Path
 

@@ -6,7 +6,7 @@
 // unique(dim=-1).  Natively the cluster id IS an index into a dense voxel-slot table
 //      slot = cx + nx*cy + nx*ny*(batch + tcell),   S = nx*ny*(B+1) slots
 // (tcell = (int)pos_t is 1 only for events at t == time_window: the reference's "last event lands
-// in the next clip's voxel" quirk, SURVEY.md section 5, reproduced here), so:
+// in the next clip's voxel" quirk of pooling.py:51-58, reproduced here), so:
 //   pool_scatter   one pass over the nodes: sample the CNN map, atomic max (order-preserving uint
 //                  encoding) or float add into the slot's feature row, integer pixel sums, count,
 //                  max member index (= the reference's perm on CPU);
@@ -647,7 +647,7 @@ __global__ void k_edge_emit(const unsigned* __restrict__ bitmap, const int* __re
 }
 
 // --------------------------------------------------------------------------- finalize + edges in two launches
-// (SURVEY 8d: the pooled levels hold 20160 / 5040 / 1260 / 315 slots at B = 8 -- every dependent launch costs more
+// (the pooled levels hold 20160 / 5040 / 1260 / 315 slots at B = 8 -- every dependent launch costs more
 // than its work.)  Launch 1, one workgroup: BOTH exclusive scans of a level in one pass over the slots --
 // occupancy (= node numbering, slot order) and out-degree popcount(bitmap) of the occupied slots (= CSR row
 // pointers; a set bit always names an occupied neighbour slot).  Launch 2: node attributes, features and the CSR

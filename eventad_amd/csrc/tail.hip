@@ -1,7 +1,7 @@
 // eventad_amd/csrc/tail.hip -- spline convolutions on the pooled graphs (layers 2-5, <=2240 nodes/clip).
 //
 // Reference: MySplineConv with the cached LUT (src/dagr/model/layers/spline_conv.py:16-78).  Its LUTs
-// for these layers are 12 MB .. 14 GB because every integer pixel offset gets its
+// for these layers are 12 MB .. 14 GB (net.py:72-89 over spline_conv.py:16-37) because every integer pixel offset gets its
 // own Cin x Cout matrix.  A LUT entry is only a 4-tap blend of the 25 kernel matrices
 // (degree-1 open B-spline, torch_spline_conv basis), so natively:
 //     Z = X . [W_0 | ... | W_24 | W_root (| W_skip)]          one fp32 MFMA GEMM per conv (gemm.hip)

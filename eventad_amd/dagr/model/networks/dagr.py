@@ -42,7 +42,7 @@ class DAGR(nn.Module):
         self.backbone.prepare()
 
     def forward(self, x, reset=True, return_targets=True, filtering=True):
-        raise NotImplementedError("DAGR detection forward is outside the EventAD hot path (SURVEY.md section 2, #2)")
+        raise NotImplementedError("DAGR detection forward is outside the EventAD hot path (EventAD only calls extract_features, models/EventAD.py:335-403)")
 
     def extract_features(self, x):
         self.eval()

@@ -1,1 +1,1 @@
-"""Input side of the path (SURVEY 8f-2): event windows in the `events_2x.h5` schema -> per-clip tensors -> pinned batch."""
+"""Input side of the path: event windows in the `events_2x.h5` schema -> per-clip tensors -> pinned batch."""

@@ -4,7 +4,7 @@ coord_proj,attention,fusion.0,fusion.3}.*, soft_attention.weight, soft_attention
 dagr_model.*), same `forward(data, labels=None, testing=False)` contract.
 
 What differs is HOW it runs.  The reference walks clips x 30 tracks in Python with >=3 device->host
-syncs per object (SURVEY.md 3.2).  Here the per-object work is a static masked formulation over all
+syncs per object.  Here the per-object work is a static masked formulation over all
 30 track slots of a clip -- hidden-state dicts become [30,H] state arrays (a missing dict entry and a
 zero state are the same thing, EventAD.py:292-296), "track present" becomes a device-side mask --
 so one clip step is a handful of batched ops, nothing syncs, and the whole step can be captured in
@@ -110,7 +110,7 @@ class EventADModel(nn.Module):
         self.soft_attention_cor = SpatialAttention(32)
         self.ce_loss = nn.CrossEntropyLoss()
         # The reference caches features under hash(str(x.sum())) -- a key two different batches can
-        # share (SURVEY.md section 5).  The attributes are kept, the cache never hits (keyed per call).
+        # share.  The attributes are kept, the cache never hits (keyed per call).
         self.batch_feature_cache = None
         self.batch_input_hash = None
         self._calls = 0

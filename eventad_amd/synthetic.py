@@ -1,4 +1,4 @@
-"""Deterministic synthetic ROL/DoTA-shaped clips.
+"""Deterministic synthetic ROL/DoTA-shaped clips (the shapes of the benchmark configurations C1-C5).
 
 Per clip c: CPU generator seeded 1234+c; x,y uniform over the sensor; t = N sorted draws from the
 last `t_span_us` of a 1 000 000 us window with the last event forced to the window end

@@ -1,4 +1,4 @@
-"""Seeded random-init weights with the reference's state-dict key names (SURVEY.md 8b).
+"""Seeded random-init weights with the reference's state-dict key names.
 
 No checkpoint exists offline (dagr_s_50.pth / best_rol.pth are external downloads), so
 benchmarks and parity tests use random-init weights of the same architecture: the same

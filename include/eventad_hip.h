@@ -1,7 +1,7 @@
 /*
  * include/eventad_hip.h -- C ABI of libeventad_hip.so (gfx950 / MI355X).
  *
- * Drop-in boundary for the EventAD hot path (SURVEY.md 8b).  The reference has no C plugin ABI:
+ * Drop-in boundary for the EventAD hot path.  The reference has no C plugin ABI:
  * its only native piece is the pybind11 torch extension `ev_graph_cuda`
  * (reference src/dagr/graph/ev_graph.cu:279-283).  Group (A) below are exactly those three
  * functions with torch tensors replaced by raw device pointers + sizes + a stream; groups (B)-(E)

@@ -1,7 +1,7 @@
 """oracle/dagr_ref.py -- TEST INFRASTRUCTURE ONLY (CPU checker, never the product path).
 
 Functional CPU restatement (torch fp32 on CPU) of the frozen DAGR backbone that
-EventAD runs under no_grad (SURVEY.md 8a rows A1, A6-A19).  Every function cites
+EventAD runs under no_grad.  Every function cites
 the reference lines it follows (paths relative to /root/reference).  Third-party
 arithmetic that is NOT in the reference tree (torch_geometric 2.6.1,
 torch_spline_conv 1.2.2, torch_cluster 1.6.3, torch_scatter 2.1.2 -- pins from

@@ -34,7 +34,7 @@ static void spiral_next(spiral_t* s) {
     }
 }
 
-/* Exported so tests can check the spiral order itself (SURVEY 8c known answers). */
+/* Exported so tests can check the spiral order itself (known answers). */
 void ora_spiral(int n, int32_t* xy) {
     spiral_t s; spiral_init(&s);
     for (int i = 0; i < n; ++i) { xy[2 * i] = s.x; xy[2 * i + 1] = s.y; spiral_next(&s); }

@@ -1,6 +1,6 @@
 """oracle/head_ref.py -- TEST INFRASTRUCTURE ONLY.
 
-CPU restatement of the EventAD head (SURVEY.md 8a rows A2-A5) in eval mode
+CPU restatement of the EventAD head in eval mode
 (dropout inactive), functional over a dict of parameter tensors whose keys are
 the reference's state-dict names.  Follows /root/reference/models/EventAD.py:
 
@@ -54,7 +54,7 @@ def process_bbox(bbox, b, node_features, node_positions, node_batch, global_feat
 
 
 def roi_features(out4, data):
-    """EventAD.py:335-403 without the feature cache (weak key) -> f32[B,2,31,64]."""
+    """EventAD.py:335-403 without the feature cache (its key is weak: shapes and sums only) -> f32[B,2,31,64]."""
     B = int(data.num_graphs)
     nf, npos, nb = out4.x, out4.pos[:, :2], out4.batch
     glob = torch.zeros((B, nf.size(1)))

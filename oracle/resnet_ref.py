@@ -1,6 +1,6 @@
 """oracle/resnet_ref.py -- TEST INFRASTRUCTURE ONLY.
 
-CPU restatement of the CNN feature branch (SURVEY.md 8a row A8):
+CPU restatement of the CNN feature branch:
 HookModule.forward (src/dagr/model/networks/net_img.py:122-134) over
 torchvision 0.16 `resnet50` (net.py:41-49; torchvision is absent here, so the
 published ResNet-50 v1.5 architecture is restated: 7x7/2 stem, 3x3/2 max-pool,

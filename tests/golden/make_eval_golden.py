@@ -1,4 +1,4 @@
-"""Golden vectors for the test/validation loop (SURVEY 8f-1), made by RUNNING THE REFERENCE in this container:
+"""Golden vectors for the test/validation loop, made by RUNNING THE REFERENCE in this container:
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_eval_golden.py
 imports /root/reference/utils/evaluation.py (numpy + sklearn) and /root/reference/utils/test.py (its
 `dagr.utils.buffers` import is served by eventad_amd.compat) and stores their inputs and outputs in

@@ -38,7 +38,7 @@ def grad_sample_index(numel, seed, n=4096):
 
 def make_head_case(seed, num_graphs, tracks, nodes_per_clip, drop_prob, empty_clip, far_box,
                    width=256, height=256):
-    """Seeded out4 nodes + boxes in the input schema of SURVEY.md 8a row A0."""
+    """Seeded out4 nodes + boxes in the path's input schema (eventad_amd/batch.py)."""
     g = torch.Generator().manual_seed(3000 + seed)
     xs, ps, bs = [], [], []
     for b in range(num_graphs):

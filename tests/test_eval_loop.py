@@ -1,4 +1,4 @@
-"""Test/validation loop (SURVEY 8f-1): eventad_amd/utils/{evaluation,test}.py against golden vectors produced by the
+"""Test/validation loop: eventad_amd/utils/{evaluation,test}.py against golden vectors produced by the
 reference's own utils/evaluation.py and utils/test.py (tests/golden/make_eval_golden.py)."""
 import io, json, os, contextlib
 import numpy as np

@@ -1,4 +1,4 @@
-"""Validation-AUC parity (BASELINE.json: "AUC within 1e-3 of reference"): >= 2000 labelled objects from the
+"""Validation-AUC parity (the bar: AUC within 1e-3 of the reference): >= 2000 labelled objects from the
 seeded generator, raw class-1 logit as the score, unadjusted ROC AUC (reference utils/visualization.py:81-82
 definition), native GPU path vs the CPU oracle."""
 import pytest

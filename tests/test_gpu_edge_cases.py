@@ -91,7 +91,7 @@ def test_single_event_batch():
 
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C5"])
 def test_full_size_properties(cfg):
-    """At BASELINE.json's full sizes (C2: 400k events; C3: 6.4M events, spiral-walk edge search; C5: 32M events at 640x480,
+    """At the full sizes of the benchmark configurations (C2: 400k events; C3: 6.4M events, spiral-walk edge search; C5: 32M events at 640x480,
     search radius 7, rank-dealt spiral walk and the partly-in-LDS LUT) the oracle is too slow for the CI budget: check
     invariants of the graph and of every pooled level instead."""
     from eventad_amd.backbone import NativeBackbone

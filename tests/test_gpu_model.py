@@ -1,6 +1,6 @@
 """GPU parity of the whole hot path through the reference's module API: DAGR.extract_features ->
 EventADModel.forward / one training step, against the CPU oracle on the same seeded input.
-Tolerance (BASELINE.json north_star): logits within 1e-3, argmax labels identical."""
+Tolerance (the build's stated bar): logits within 1e-3, argmax labels identical."""
 import pytest
 import torch
 

@@ -50,7 +50,7 @@ def test_state_dict_keys_match_reference_contract():
     m = EventADModel(torch.nn.Module())
     sd = m.state_dict()
     assert {k: tuple(v.shape) for k, v in sd.items()} == HEAD_SHAPES
-    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 1115234
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 1115234      # trainable parameters of the reference head (GRUs, fusion, attention, classifier)
 
 
 def test_no_objects_gives_zero_loss_with_grad():

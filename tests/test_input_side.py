@@ -1,4 +1,4 @@
-"""Input side (SURVEY 8f-2): window selection in the events_2x.h5 schema, clip assembly, collation, and the HIP
+"""Input side: window selection in the events_2x.h5 schema, clip assembly, collation, and the HIP
 format_data against the torch one."""
 import numpy as np
 import pytest

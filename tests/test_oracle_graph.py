@@ -1,4 +1,4 @@
-"""Hand-derived known answers for the graph-builder oracle (SURVEY.md 8c list).
+"""Hand-derived known answers for the graph-builder oracle.
 The reference has no tests for src/dagr/graph; these pin oracle/graph_ref.c."""
 import torch
 

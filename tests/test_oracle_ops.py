@@ -57,7 +57,7 @@ def test_grid_cluster_and_t_equals_one_quirk():
     pos = torch.tensor([[0.0, 0.0, 0.5, 0], [255 / 256, 255 / 256, 0.2, 0], [0.0, 0.0, 1.0, 0],
                         [0.0, 0.0, 0.1, 1], [10 / 256, 0.0, 0.3, 2]])
     c = R.grid_cluster(pos, vs, torch.Tensor([0, 0, 0, 0]), torch.Tensor([.9999999, .9999999, .9999999, 2]))
-    # the t==1.0 event of clip 0 lands in clip 1's voxel
+    # the t==1.0 event of clip 0 lands in clip 1's voxel (pooling.py:51-58 clusters t == time_window into the next plane)
     assert c.tolist() == [0, 55 + 56 * 39, 2240, 2240, 2 + 2 * 2240]
 
 
