@@ -7,7 +7,7 @@
 // The reference gathers LUT[dx,dy] into an [E,Cin,Cout] temporary (36.6 GB in its own comment,
 // spline_conv.py:43-44) and scatter-adds.  Here every destination owns <=16 contiguous ELL slots
 // (graph.hip), the LUT (one Cin x 16 matrix per spiral step, 49 steps at r=3) lives in LDS (at larger radii: its inner
-// rings, as many as fit), and the 4 lanes of a
+// rings, as many as fit into 152 KiB shared by the 16 waves of a CU), and the 4 lanes of a
 // destination split the INPUT channels: no atomics, no temporary.
 //
 // Weights arrive pre-multiplied by the folded eval-mode BatchNorm scale of their output column (host side:
@@ -33,7 +33,7 @@
 // Messages are added in ELL slot order (self edge, then spiral order) = the reference's edge order.
 #include "common.h"
 
-#define L1_THREADS 512          // 8 waves share one LDS copy of the LUT: 2 workgroups/CU = 16 waves/CU
+#define L1_THREADS 512          // 8 waves share one LDS copy of the LUT: 2 workgroups/CU = 16 waves/CU (a table that does not fit 80 KiB: 16 waves, one copy of 152 KiB)
 #define L1_GROUP 64             // destinations ranked together (4 passes of 16)
 #define L1_ITEM_PASSES 2        // passes per work item: a wave's last item is the kernel's tail, so items are half groups
 #define L1_MAX_WG 512
@@ -125,8 +125,8 @@ __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float
     l1_load_row<CINP>(xin, src, j, xv[S], xe[S]);
 }
 
-template <int CINP, bool SKIP, bool ALL_IN_LDS>
-__global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
+template <int CINP, bool SKIP, bool ALL_IN_LDS, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
                                                  const uint16_t* __restrict__ ell_step, const int* __restrict__ deg,
                                                  const float* __restrict__ lut, const float* __restrict__ shift,
                                                  const float* __restrict__ xskip, const float* __restrict__ wskip,
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(L1_THREADS, 4) void k_l1_conv(const float* __restri
         const float4* g4 = (const float4*)lut;
         float4* s4 = (float4*)s_lut;
         const int n4 = nlds * LS / 4, m4 = 2 * LS / 4, skip4 = (steps - nlds) * LS / 4;
-        for (int t = tid; t < n4 + m4; t += L1_THREADS) s4[t] = g4[t < n4 ? t : t + skip4];
+        for (int t = tid; t < n4 + m4; t += THREADS) s4[t] = g4[t < n4 ? t : t + skip4];
     }
     if (SKIP) { if (tid < 80) ((float4*)s_skip)[tid] = ((const float4*)wskip)[tid]; }
     __syncthreads();                                      // the only workgroup barrier: from here on every wave is on its own
@@ -251,22 +251,28 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     constexpr int LS = CINP * 16;
     if (max_nb != 16) return EVAD_ERR_ARG;              // an ELL row is read as 4 x int4 + 4 x uint2
     if ((unsigned long long)N * 80ull > 0xffffffffull) return EVAD_ERR_ARG;     // 32-bit byte offsets into the row arrays (53 M events)
-    const size_t fixed = sizeof(float) * (SKIP ? 320 : 0), budget = 80 * 1024;   // two workgroups per CU (160 KiB LDS)
+    // LDS: the whole table when two 8-wave workgroups per CU can each hold it (80 KiB; radius <= 3); else ONE 16-wave
+    // workgroup per CU with 152 KiB -- twice the inner rings in LDS for the same 16 waves per CU
+    const size_t fixed = sizeof(float) * (SKIP ? 320 : 0);
+    const bool whole = fixed + sizeof(float) * (size_t)(steps + 2) * LS <= 80 * 1024;
+    const size_t budget = whole ? 80 * 1024 : 152 * 1024;
     int nlds = (int)((budget - fixed) / (sizeof(float) * LS)) - 2;               // spiral steps whose matrices fit beside the 2 special ones
     if (nlds > steps) nlds = steps;
     const size_t lds = fixed + sizeof(float) * (size_t)(nlds + 2) * LS;
     const int ngroups = (int)evad_blocks(N, L1_GROUP);
-    int wgs = (ngroups + 7) / 8;                        // at least one 8-wave workgroup per 8 groups ...
-    if (wgs > L1_MAX_WG) wgs = L1_MAX_WG;               // ... at most two per CU: the waves pull groups until none is left
+    const int threads = whole ? L1_THREADS : 2 * L1_THREADS, waves = threads / 64;
+    int wgs = (ngroups + waves - 1) / waves;            // at least one workgroup per `waves` groups ...
+    const int max_wg = whole ? L1_MAX_WG : L1_MAX_WG / 2;
+    if (wgs > max_wg) wgs = max_wg;                     // ... at most 16 waves per CU: the waves pull groups until none is left
     wgs = (wgs + 7) / 8 * 8;                            // every XCD gets the same number of workgroups
-    dim3 grid((unsigned)wgs), block(L1_THREADS);
+    dim3 grid((unsigned)wgs), block((unsigned)threads);
     static size_t attr_set[2] = {0, 0};                 // raise the dynamic-LDS limit once per size (not a stream op)
-    if (nlds == steps) {
-        auto kern = k_l1_conv<CINP, SKIP, true>;
+    if (nlds == steps && whole) {
+        auto kern = k_l1_conv<CINP, SKIP, true, L1_THREADS>;
         if (attr_set[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = lds; }
         hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
     } else {                                // large radius: inner rings in LDS, outer rings read from global memory / L2
-        auto kern = k_l1_conv<CINP, SKIP, false>;
+        auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS>;
         if (attr_set[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = lds; }
         hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
     }
