@@ -303,6 +303,11 @@ class TrainStep:
         if n <= 0:
             n = 3 if (d["masked"] and native is not None and getattr(data, "image_feats", None) is not None) else 2
         n = max(2, n)
+        if n > 2 and not d["masked"]:
+            # Two backbone passes in flight beside an unpartitioned head: a run of the 32 M-event stress configuration in
+            # this mode ended in a GPU memory fault whose cause is not established -- refused until it is.
+            raise RuntimeError("TrainStep: more than two backbone chains need the CU-partitioned head (EVENTAD_HEAD_CUS > 0 or "
+                               "a workload where the partition is chosen automatically); EVENTAD_BACKBONE_CHAINS=%d refused" % n)
         while len(d["gb"]) < n:
             add_chain()
         d["n"] = n
