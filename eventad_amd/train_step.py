@@ -303,11 +303,12 @@ class TrainStep:
         if n <= 0:
             n = 3 if (d["masked"] and native is not None and getattr(data, "image_feats", None) is not None) else 2
         n = max(2, n)
-        if n > 2 and not d["masked"]:
-            # Two backbone passes in flight beside an unpartitioned head: a run of the 32 M-event stress configuration in
-            # this mode ended in a GPU memory fault whose cause is not established -- refused until it is.
-            raise RuntimeError("TrainStep: more than two backbone chains need the CU-partitioned head (EVENTAD_HEAD_CUS > 0 or "
-                               "a workload where the partition is chosen automatically); EVENTAD_BACKBONE_CHAINS=%d refused" % n)
+        if n > 2 and not d["masked"] and int(data.pos.shape[0]) > 8_000_000:
+            # Two backbone passes in flight beside an unpartitioned head run in the tests (small batches) and ran at 6.4 M
+            # events; at 32 M events (12 GB workspace sets) a run in this mode ended in a GPU memory fault whose cause is
+            # not established -- refused at that scale until it is.
+            raise RuntimeError("TrainStep: EVENTAD_BACKBONE_CHAINS=%d without the CU-partitioned head is refused for batches of "
+                               "more than 8 M events" % n)
         while len(d["gb"]) < n:
             add_chain()
         d["n"] = n
