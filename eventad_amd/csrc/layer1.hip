@@ -125,7 +125,7 @@ __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float
     l1_load_row<CINP>(xin, src, j, xv[S], xe[S]);
 }
 
-template <int CINP, bool SKIP, bool ALL_IN_LDS, int THREADS>
+template <int CINP, bool SKIP, bool ALL_IN_LDS, int THREADS, bool BY_TAIL>
 __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict__ xin, const int* __restrict__ ell_src,
                                                  const uint16_t* __restrict__ ell_step, const int* __restrict__ deg,
                                                  const float* __restrict__ lut, const float* __restrict__ shift,
@@ -154,6 +154,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     const float4 sh = *(const float4*)(shift + 4 * j);
     const float* wlds = s_lut + j * 16;
     const float* wglb = lut + j * 16;
+    constexpr bool by_tail = BY_TAIL;                     // rank the rows of a group by their outer tail, see below (the host's choice)
+    static_assert(!(BY_TAIL && ALL_IN_LDS), "a table that is resident as a whole has no outer tail");
     // Work items: groups of 64 consecutive destinations, handed out by one counter per XCD (blockIdx & 7: workgroups are dealt
     // round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so the
     // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
@@ -182,6 +184,34 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
             if (d_l == v) rank = base + __popcll(m & lt_mask);
             base += __popcll(m);
         }
+        if (by_tail) {
+            // Large radius: a slot reads its matrices from global memory for the whole wave as soon as ONE of the pass's 16
+            // rows has a cell outside the LDS-resident rings there.  Cells ascend along a row (spiral order), so a row's
+            // outer cells are its tail: ranking the rows by the slot where that tail begins (rows without one first), and
+            // by degree only among equals, gathers the rows that need the slow branch from early on into the same passes.
+            // (Two stable rankings, least significant key first: the degree ranking above, then this one over its order.)
+            // Only where most of the table is NOT resident: at 640x480 (117 of 225 cells resident, 2 % of the rows with a tail)
+            // the second ranking costs more than it saves (C5 conv1 8.5 -> 9.1 ms), at 1280x720 (117 of 729) it takes C4's two
+            // convolutions from 4.0 + 3.1 to 3.1 + 2.0 ms.
+            const uint4* srow = (const uint4*)((const char*)ell_step + (size_t)min(n0 + lane, N - 1) * 32u);
+            const uint4 s0 = srow[0], s1 = srow[1];
+            const unsigned w[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            unsigned outer = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                outer |= ((int)(w[k] & 0xffffu) >= nlds ? 1u : 0u) << (2 * k) | ((int)(w[k] >> 16) >= nlds ? 1u : 0u) << (2 * k + 1);
+            outer &= (1u << d_l) - 1u & ~1u;                                 // live slots only; slot 0 is the self edge
+            const int f_l = outer ? __ffs((int)outer) - 1 : 16;
+            const int f_r = __builtin_amdgcn_ds_permute(rank << 2, f_l);     // position r of the degree order <- its row's f
+            int rank2 = 0, base2 = 0;
+#pragma unroll
+            for (int v = 16; v >= 0; --v) {
+                const unsigned long long m = __ballot(f_r == v);
+                if (f_r == v) rank2 = base2 + __popcll(m & lt_mask);
+                base2 += __popcll(m);
+            }
+            rank = __builtin_amdgcn_ds_bpermute(rank << 2, rank2);           // this row's place in the final order
+        }
         const int perm = __builtin_amdgcn_ds_permute(rank << 2, lane);      // lane r <- the lane whose rank is r
         const int dperm = __builtin_amdgcn_ds_permute(rank << 2, d_l);
         int nl = __shfl(perm, 16 * p0 + q, 64), d = __shfl(dperm, 16 * p0 + q, 64);
@@ -197,8 +227,16 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
         }
 #pragma unroll 1
         for (int p = p0; p < p0 + L1_ITEM_PASSES; ++p) {
-            const int dmax = __builtin_amdgcn_readfirstlane(d);            // quad 0 of the pass has the longest row
-            if (dmax == 0) break;
+            int dmax;
+            if (!by_tail) {
+                dmax = __builtin_amdgcn_readfirstlane(d);                  // ranked by degree: quad 0 of the pass has the longest row
+                if (dmax == 0) break;                                      // ... and the passes after an empty one are empty
+            } else {                                                       // ranked by the outer tail first: any quad may
+                int m = d;
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) m = max(m, __shfl_xor(m, o, 64));
+                dmax = __builtin_amdgcn_readfirstlane(m);
+            }
             const int node = n0 + nl;
             // the next pass's row (ELL slots + degree) is fetched now
             const bool more = p + 1 < p0 + L1_ITEM_PASSES;
@@ -207,6 +245,14 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
             const int safe2 = min(n0 + nl2, N - 1);
             const int4 sv2 = ld_off<int4>(ell_src, (unsigned)safe2 * 64u + 16u * (unsigned)j);
             const uint2 cv2 = ld_off<uint2>(ell_step, (unsigned)safe2 * 32u + 8u * (unsigned)j);
+            if (by_tail && dmax == 0 && more) {
+                // an empty pass in front of one that is not (possible only in this ranking): no block runs, so the next pass's
+                // first rows, which a pass's last block requests, are requested here
+                const int t0 = quad_bcast<0>(sv2.x), t1 = quad_bcast<0>(sv2.y), t2 = quad_bcast<0>(sv2.z), t3 = quad_bcast<0>(sv2.w);
+                const int nxt[4] = {t0, t1, t2, t3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d2 ? nxt[u] : safe2, j, xv[u], xe[u]);
+            }
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f); float ke = 0.f;
             if (SKIP) l1_load_row<20>(xskip, safe, j, kv, ke);
             float4 acc[4];
@@ -268,13 +314,20 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     dim3 grid((unsigned)wgs), block((unsigned)threads);
     static size_t attr_set[2] = {0, 0};                 // raise the dynamic-LDS limit once per size (not a stream op)
     if (nlds == steps && whole) {
-        auto kern = k_l1_conv<CINP, SKIP, true, L1_THREADS>;
+        auto kern = k_l1_conv<CINP, SKIP, true, L1_THREADS, false>;
         if (attr_set[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = lds; }
         hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
     } else {                                // large radius: inner rings in LDS, outer rings read from global memory / L2
-        auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS>;
-        if (attr_set[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = lds; }
-        hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
+        static size_t attr_tail = 0;
+        if (3 * nlds < steps) {             // most of the table is not resident: rows ranked by their outer tail (see the kernel)
+            auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, true>;
+            if (attr_tail < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_tail = lds; }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
+        } else {
+            auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, false>;
+            if (attr_set[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = lds; }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
+        }
     }
     return evad_last_error();
 }
