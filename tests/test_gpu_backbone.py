@@ -54,7 +54,7 @@ def test_backbone_matches_oracle(W, H, n, B, span):
 BIG_CASES = [(640, 480, 60000, 2, 12000), (640, 480, 20000, 2, 50000), (1280, 720, 80000, 2, 12000), (1280, 720, 12000, 3, 50000)]
 
 
-# ell_variant 2 forces the wave-per-pixel edge search (the default at two or more events per pixel) on these sparse
+# ell_variant 2 forces the wave-per-pixel edge search (the default from 0.4 events per pixel) on these sparse
 # inputs: 4 and 12 passes of 64 spiral steps, mostly empty neighbour pixels
 @pytest.mark.parametrize("ell_variant", [None, 2])
 @pytest.mark.parametrize("W,H,n,B,span", BIG_CASES)
