@@ -54,6 +54,34 @@ def test_backbone_matches_oracle(W, H, n, B, span):
 BIG_CASES = [(640, 480, 60000, 2, 12000), (640, 480, 20000, 2, 50000), (1280, 720, 80000, 2, 12000), (1280, 720, 12000, 3, 50000)]
 
 
+def test_large_radius_convolution_with_a_ragged_last_group():
+    """Radius 13, 150 events crowded into a 40 x 40 corner: rows with neighbours in the outer rings (cells that are not
+    LDS-resident) and a last group of 64 destinations that is mostly empty -- with the rows ranked by their outer tail, the
+    empty rows form whole passes IN FRONT of the ones that hold rows."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    W, H, B = 1280, 720, 1
+    raw = synthetic.make_batch(W, H, 150, B, with_image=False, precomputed_feats=True, t_span_us=12000)
+    g = torch.Generator().manual_seed(9)
+    raw.pos[:, 0] = torch.randint(0, 40, (150,), generator=g).to(raw.pos.dtype)
+    raw.pos[:, 1] = torch.randint(0, 40, (150,), generator=g).to(raw.pos.dtype)
+    data = dagr_ref.format_data(raw)
+    sd = weights.random_graph_state()
+    cfg = dagr_ref.make_config(W, H, B)
+    (o3, o4), stages = dagr_ref.backbone_forward(sd, data, cfg, data.image_feats, return_all=True, mode="ondemand")
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(sd, W, H, dev)
+    res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    torch.cuda.synchronize()
+    assert nb.check_flags() & ~1 == 0
+    N = data.pos.shape[0]
+    steps = res["ws"]["ell_step"][:N].long() & 0xffff
+    deg = res["ws"]["deg"][:N].long()
+    live = torch.arange(16, device=dev)[None, :] < deg[:, None]
+    assert int((live & (steps >= 117)).sum()) > 50               # outer-ring cells are really used
+    _check(data, cfg, (o3, o4), stages, nb, res)
+
+
 # ell_variant 2 forces the wave-per-pixel edge search (the default from 0.4 events per pixel) on these sparse
 # inputs: 4 and 12 passes of 64 spiral steps, mostly empty neighbour pixels
 @pytest.mark.parametrize("ell_variant", [None, 2])
