@@ -174,7 +174,12 @@ def main():
             else:
                 ts.capture(data)
                 run = ts.replay
-        except Exception as e:                                 # e.g. a collective that cannot be captured: launch eagerly
+        except Exception as e:
+            if world > 1:
+                # the multi-GPU number is defined on the captured pipeline (all-reduce inside the head graph): an eager run
+                # in its place would be a different measurement under the same name
+                print("[bench] rank %d: hipGraph capture failed (%s: %s)" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+                raise SystemExit(3)
             print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e), file=sys.stderr)
             torch.cuda.synchronize()
             use_graph = pipelined = False

@@ -177,11 +177,41 @@ __global__ void k_conv_reduce(ConvP p, long long MN) {
     p.out[t] = v;
 }
 
+// Tile size and split-K factor of one convolution.  Shapes whose output has too few tiles to fill the chip (the 3x3 and
+// wide 1x1 convolutions of ResNet layers 3-4: 64-128 tiles for 256 CUs) run split-K when a workspace of `have` floats
+// can hold the slabs; have < 0: as many as the shape wants (the size query).
+static long long conv_plan(long long M, int Cout, int K, long long have, bool& big, int& ksplit, int& kchunk) {
+    const long long MN = M * Cout;
+    big = MN >= 128ll * 128 * 64 && Cout >= 128;
+    const int bt = big ? 128 : 64;
+    const long long tiles = ((Cout + bt - 1) / bt) * ((M + bt - 1) / bt);
+    ksplit = 1; kchunk = 0;
+    if (have != 0 && tiles < 160 && K >= 512) {
+        int ks = (int)(512 / tiles);
+        if (ks > 8) ks = 8;
+        while (ks > 1 && (K / ks < 128 || (have > 0 && (long long)ks * MN > have))) --ks;
+        if (ks > 1) {
+            kchunk = ((K + ks - 1) / ks + CBK - 1) / CBK * CBK;
+            ksplit = (K + kchunk - 1) / kchunk;
+            return (long long)ks * MN;                        // what the choice of ks was checked against
+        }
+    }
+    return 0;
+}
+
+/* Floats of split-K workspace eventad_conv2d_nhwc uses for this shape when it is given at least that many (0: the shape
+ * runs in one pass).  Passes that may overlap in time on one GPU need a workspace each. */
+extern "C" int eventad_conv2d_workspace_floats(int B, int OH, int OW, int Cin, int Cout, int KH, int KW, int64_t* floats) {
+    if (!floats || B <= 0 || OH <= 0 || OW <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return EVAD_ERR_ARG;
+    bool big; int ks, kc;
+    const long long M = (long long)B * OH * OW;
+    *floats = conv_plan(M, Cout, KH * KW * Cin, -1, big, ks, kc);
+    return 0;
+}
+
 /* in f32[B,IH,IW,Cin] (NHWC, Cin % 4 == 0), w f32[KH*KW*Cin, Cout] (k = (kh*KW+kw)*Cin+ci, Cout % 4 == 0),
  * out f32[B,OH,OW,Cout]; epilogue: +bias, *scale+shift (folded BatchNorm), +residual (same shape as out), ReLU.
- * workspace (nullable) f32[workspace_floats]: shapes whose output has too few tiles to fill the chip (the 3x3 and
- * wide 1x1 convolutions of ResNet layers 3-4: 64-128 tiles for 256 CUs) are then computed split-K, slabs summed in
- * order by a second launch. */
+ * workspace (nullable) f32[workspace_floats]: split-K slabs (conv_plan), summed in slab order by a second launch. */
 extern "C" int eventad_conv2d_nhwc(const float* in, const float* w, float* out, const float* bias, const float* scale,
                                    const float* shift, const float* residual, int B, int IH, int IW, int Cin, int OH,
                                    int OW, int Cout, int KH, int KW, int stride, int pad, int relu, float* workspace,
@@ -193,18 +223,10 @@ extern "C" int eventad_conv2d_nhwc(const float* in, const float* w, float* out, 
     ConvP p{in, w, out, bias, scale, shift, residual, B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, relu, nullptr, 1, 0};
     const long long M = (long long)B * OH * OW, MN = M * Cout;
     const int K = KH * KW * Cin;
-    const bool big = M * Cout >= 128ll * 128 * 64 && Cout >= 128;
+    bool big;
+    conv_plan(M, Cout, K, (workspace && workspace_floats > 0) ? workspace_floats : 0, big, p.ksplit, p.kchunk);
+    if (p.ksplit > 1) p.part = workspace;
     const int bt = big ? 128 : 64;
-    const long long tiles = ((Cout + bt - 1) / bt) * ((M + bt - 1) / bt);
-    if (workspace && tiles < 160 && K >= 512) {
-        int ks = (int)(512 / tiles);
-        if (ks > 8) ks = 8;
-        while (ks > 1 && (K / ks < 128 || (long long)ks * MN > workspace_floats)) --ks;
-        if (ks > 1) {
-            p.ksplit = ks; p.kchunk = ((K + ks - 1) / ks + CBK - 1) / CBK * CBK; p.part = workspace;
-            p.ksplit = (K + p.kchunk - 1) / p.kchunk;
-        }
-    }
     dim3 grid((Cout + bt - 1) / bt, (unsigned)((M + bt - 1) / bt), p.ksplit);
     const bool c16 = Cin % CBK == 0;                         // then K and every split-K chunk are multiples of the slab depth
     if (big) { if (c16) hipLaunchKernelGGL((k_conv_f32<2, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -7,6 +7,8 @@ The nn.Conv2d / nn.BatchNorm2d modules below only HOLD the parameters under torc
 kernels of csrc/cnn.hip through the C ABI (`NativeCNN`).  Only what EventAD consumes is computed: the
 five feature taps (raw conv1 output, layer1..4) through their 1x1 reducers; avgpool/fc and
 `output_dconv` (detection-head inputs, net_img.py:131-133) are skipped."""
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -116,32 +118,63 @@ class NativeCNN:
                 self.blocks.append(d)
             self.blocks[-1]["tap"] = True
         self.red = [(_wk(c), c.bias.detach().float().contiguous()) for c in hook.feature_dconv]
-        self._key = None
+        self._need, self._plan, self._ws = {}, None, None
 
     def _conv(self, x, w, B, IH, IW, Cin, Cout, K, stride, pad, bias=None, bn=None, residual=None, relu=0, out=None):
         OH, OW = (IH + 2 * pad - K) // stride + 1, (IW + 2 * pad - K) // stride + 1
+        if self._plan is not None:                          # sizing pass: which split-K scratch does this shape want?
+            n = ctypes.c_int64(0)
+            call("eventad_conv2d_workspace_floats", B, OH, OW, Cin, Cout, K, K, ctypes.byref(n))
+            self._plan = max(self._plan, n.value)
+            return None, OH, OW
         if out is None:
             out = torch.empty((B, OH, OW, Cout), device=self.dev)
-        # split-K scratch for the shapes that cannot fill 256 CUs on their own (layers 3-4): up to 8 slabs of the largest
-        # such output (<= 160 tiles of 128 x 128)
-        if getattr(self, "_ws", None) is None:
-            self._ws = torch.empty(8 * 160 * 128 * 128, device=self.dev)
+        ws = self._ws
         call("eventad_conv2d_nhwc", ptr(x), ptr(w), ptr(out), ptr(bias), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
-             ptr(residual), B, IH, IW, Cin, OH, OW, Cout, K, K, stride, pad, relu, ptr(self._ws), self._ws.numel(),
+             ptr(residual), B, IH, IW, Cin, OH, OW, Cout, K, K, stride, pad, relu, ptr(ws), ws.numel() if ws is not None else 0,
              torch.cuda.current_stream().cuda_stream)
         return out, OH, OW
 
+    def workspace_floats(self, B, H, W):
+        """Largest split-K scratch any convolution of a pass over [B,3,H,W] images wants (shapes that cannot fill 256 CUs
+        on their own: layers 3-4)."""
+        key = (B, H, W)
+        if key not in self._need:
+            self._plan = 0
+            try:
+                self._run(None, B, H, W)
+                self._need[key] = self._plan
+            finally:
+                self._plan = None
+        return self._need[key]
+
     def forward(self, image):
         B, _, H, W = image.shape
-        st = torch.cuda.current_stream().cuda_stream
-        image = image.contiguous().float()
-        x0 = torch.empty((B, H, W, 4), device=self.dev)
-        call("eventad_image_to_nhwc4", ptr(image), ptr(x0), B, H, W, st)
+        # The split-K scratch belongs to THIS pass: slab partials written by a convolution are summed by the launch behind
+        # it, so two passes in flight (backbone graphs of consecutive batches on different streams) must not share one.
+        # Allocated per call, it comes from the stream's pool of torch's allocator when run eagerly and from the graph's
+        # private pool under capture.
+        need = self.workspace_floats(B, H, W)
+        self._ws = torch.empty(need, device=self.dev) if need else None
+        try:
+            return self._run(image.contiguous().float(), B, H, W)
+        finally:
+            self._ws = None
+
+    def _run(self, image, B, H, W):
+        plan = image is None
+        st = None if plan else torch.cuda.current_stream().cuda_stream
+        x0 = None
+        if not plan:
+            x0 = torch.empty((B, H, W, 4), device=self.dev)
+            call("eventad_image_to_nhwc4", ptr(image), ptr(x0), B, H, W, st)
         c1, h, w = self._conv(x0, self.stem_w, B, H, W, 4, 64, 7, 2, 3)                     # hook on `conv1`: raw output
         taps = [(c1, h, w, 64)]
         ph, pw = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
-        x = torch.empty((B, ph, pw, 64), device=self.dev)
-        call("eventad_bn_relu_maxpool", ptr(c1), ptr(self.stem_bn[0]), ptr(self.stem_bn[1]), ptr(x), B, h, w, 64, ph, pw, st)
+        x = None
+        if not plan:
+            x = torch.empty((B, ph, pw, 64), device=self.dev)
+            call("eventad_bn_relu_maxpool", ptr(c1), ptr(self.stem_bn[0]), ptr(self.stem_bn[1]), ptr(x), B, h, w, 64, ph, pw, st)
         h, w, cin = ph, pw, 64
         for d in self.blocks:
             pl, s = d["planes"], d["stride"]

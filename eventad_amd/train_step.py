@@ -82,14 +82,19 @@ class TrainStep:
         self.nh.keep_superseded_workspaces = True
 
     def snapshot(self):
-        """Head weights + optimiser state (flat buffers, ~14 MB), e.g. to undo warm-up steps."""
+        """Head weights + optimiser state (flat buffers, ~14 MB) and the device's random generator state (dropout masks),
+        e.g. to undo warm-up steps."""
         nh = self.nh
-        return [t.clone() for t in (nh.flat, nh.exp_avg, nh.exp_avg_sq, nh.opt_state)]
+        return [t.clone() for t in (nh.flat, nh.exp_avg, nh.exp_avg_sq, nh.opt_state)] + [torch.cuda.get_rng_state(nh.flat.device)]
 
     def restore(self, snap):
+        """Not inside a graph capture (the generator state is set from the host)."""
         nh = self.nh
         for dst, src in zip((nh.flat, nh.exp_avg, nh.exp_avg_sq, nh.opt_state), snap):
             dst.copy_(src)
+        if len(snap) > 4:
+            torch.cuda.synchronize(nh.flat.device)
+            torch.cuda.set_rng_state(snap[4], nh.flat.device)
 
     # -------------------------------------------------------------------- eager
     def step(self, data, labels=None):
@@ -101,7 +106,8 @@ class TrainStep:
     # ---- hipGraph: the whole step (backbone + ROI + head fwd/bwd + all-reduce + clip/AdamW) has no host sync, so it
     # can be captured once and replayed.  The captured buffers are static: `data` itself is the graph's input -- copy
     # each new batch of the same shapes INTO it (TrainStep.load_into(data, batch)) on the replaying stream before replay().
-    # Capturing runs warm-up steps and then restores weights and optimiser state: it has no side effect on the model.
+    # Capturing runs warm-up steps and then restores weights, optimiser state and the random generator: it has no side
+    # effect on the model or on the dropout masks of the steps that follow.
     def capture(self, data, labels=None, warmup=3):
         body = lambda: self.step(data, labels)
         snap = self.snapshot()                                 # the warm-up steps are real steps: undone below, so that
@@ -271,8 +277,13 @@ class TrainStep:
                     feats = self.model.extract_features(in_b[c], frames=(1,))
                     if masks is not None:
                         self.nh.fill_masks(masks)
+                # the head's loss and gradient norm live in the ONE head workspace every chain shares: each head graph ends
+                # by copying them into two floats of its own, so a step's results stay readable until the chain's next turn
+                res = torch.zeros(2, device=in_h[c].bbox.device)
                 with torch.cuda.graph(gh, capture_error_mode="thread_local"):
-                    out = self._head_update(feats, in_h[c], masks=masks)
+                    loss, norm = self._head_update(feats, in_h[c], masks=masks)
+                    self._copy_pairs([(res[0:1], loss.reshape(1)), (res[1:2], norm.reshape(1))])
+                out = (res[0], res[1])
                 if native is not None:
                     native.select_workspace(0)
             d["gb"].append(gb); d["gh"].append(gh); d["feats"].append(feats); d["out"].append(out)
@@ -303,12 +314,11 @@ class TrainStep:
         if n <= 0:
             n = 3 if (d["masked"] and native is not None and getattr(data, "image_feats", None) is not None) else 2
         n = max(2, n)
-        if n > 2 and not d["masked"] and int(data.pos.shape[0]) > 8_000_000:
-            # Two backbone passes in flight beside an unpartitioned head run in the tests (small batches) and ran at 6.4 M
-            # events; at 32 M events (12 GB workspace sets) a run in this mode ended in a GPU memory fault whose cause is
-            # not established -- refused at that scale until it is.
-            raise RuntimeError("TrainStep: EVENTAD_BACKBONE_CHAINS=%d without the CU-partitioned head is refused for batches of "
-                               "more than 8 M events" % n)
+        if n > 2 and not d["masked"]:
+            # More than two chains without the CU partition (every stream on the whole chip): at 32 M events a run in this
+            # mode ended in a GPU memory fault whose cause is not established.  Refused at every size until it is.
+            raise RuntimeError("TrainStep: %d backbone chains need the CU-partitioned head (EVENTAD_HEAD_CUS > 0, or a head that "
+                               "takes more than 0.3 of its backbone's time); without it at most 2 chains are allowed" % n)
         while len(d["gb"]) < n:
             add_chain()
         d["n"] = n
@@ -395,8 +405,8 @@ class TrainStep:
     def replay_dual(self, next_batch=None, join=True):
         """One pipelined step: head update of the batch loaded by the previous call (or capture_dual) || backbone of
         `next_batch` (formatted; on the device or in pinned host memory; None = the chain whose turn it is runs the batch it
-        holds again).  Returns (loss, grad_norm) of the batch the head consumed -- static device tensors of that chain, valid
-        after a synchronisation and until the chain's next turn (n calls later).  join=False: no per-step barrier with the
+        holds again).  Returns (loss, grad_norm) of the batch the head consumed -- two floats owned by that chain, written at
+        the end of its head graph: valid after a synchronisation and until the chain's next turn (n calls later).  join=False: no per-step barrier with the
         caller's stream (what lets more than one backbone pass be in flight); call flush() -- or synchronise -- before
         reading results or re-using the memory of a `next_batch` passed earlier."""
         d = self._dual

@@ -322,6 +322,10 @@ int eventad_conv2d_nhwc(const float* in, const float* w, float* out, const float
                         const float* shift, const float* residual, int B, int IH, int IW, int Cin, int OH, int OW,
                         int Cout, int KH, int KW, int stride, int pad, int relu, float* workspace,
                         int64_t workspace_floats, void* stream);
+/* Floats of split-K workspace eventad_conv2d_nhwc uses for this shape when given at least that many (0: one pass).
+ * No counterpart in the reference (cuDNN manages its own workspaces).  The workspace is written by the convolution launch
+ * and read by the slab-sum launch behind it: passes that may overlap in time on one GPU need a workspace each. */
+int eventad_conv2d_workspace_floats(int B, int OH, int OW, int Cin, int Cout, int KH, int KW, int64_t* floats);
 /* stem: bn1 + ReLU + 3x3/2 max-pool (pad 1), NHWC. */
 int eventad_bn_relu_maxpool(const float* in, const float* scale, const float* shift, float* out, int B, int IH, int IW,
                             int C, int OH, int OW, void* stream);
