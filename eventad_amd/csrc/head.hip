@@ -498,6 +498,42 @@ extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dropout masks of a training step (nn.GRU(dropout=.3) between the GRU layers, nn.Dropout(.3) in the fusion MLP:
+// models/EventAD.py:26,86) from a counter-based generator: mask[i] = keep ? 1/p : 0 with the random word
+// Philox4x32-10(key = seed, counter = (i / 4, step)).  A step's masks depend on (seed, step, i) only -- not on a generator
+// state that launches on other streams advance -- so every launch form of the step (eager, one hipGraph, several backbone
+// graphs in flight, each reading its step number from its own device word) draws the same masks for the same step.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+
+__global__ void k_dropout_masks(float* __restrict__ out, long long n, float keep, float scale, uint64_t seed, int64_t step,
+                                const int64_t* __restrict__ step_dev) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // 4 values per thread
+    if (q * 4 >= n) return;
+    const uint64_t s = (uint64_t)(step_dev ? *step_dev : step);
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)s, (uint32_t)(s >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ((c[j] >> 8) * (1.0f / 16777216.0f)) < keep ? scale : 0.f;   // 24-bit uniform in [0,1)
+    if (q * 4 + 3 < n) *(float4*)(out + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    else for (int j = 0; q * 4 + j < n; ++j) out[q * 4 + j] = v[j];
+}
+
+extern "C" int eventad_dropout_masks(float* out, int64_t n, double keep_prob, int64_t seed, int64_t step,
+                                     const int64_t* step_dev, void* stream) {
+    if (!out || n <= 0 || !(keep_prob > 0.0 && keep_prob <= 1.0) || ((uintptr_t)out & 15)) return EVAD_ERR_ARG;
+    hipLaunchKernelGGL(k_dropout_masks, dim3(evad_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n,
+                       (float)keep_prob, (float)(1.0 / keep_prob), (uint64_t)seed, step, step_dev);
+    return evad_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Streams restricted to a set of CUs (default priority): the training step can give the head's chain of small launches a
 // few CUs of its own, so that its workgroups do not queue behind the chip-wide grids of the event-level kernels.
 // mask: bit i set = CU i may be used; words = number of 32-bit words.

@@ -62,6 +62,12 @@ class NativeHead:
                                                            # autograd would add the bridge's result onto itself)
             self.P[name], self.G[name] = v, g
         self._B = None
+        # dropout masks come from a counter-based generator (eventad_dropout_masks): the masks of step k depend on (seed, k)
+        # only.  mask_step counts the steps whose masks were drawn; a captured draw reads its step number from a device word
+        # that the replaying host sets (next_mask_step).
+        self.mask_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        self.mask_step = 0
+        self.mask_step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         # launch form of the clip recurrence: one fused launch per stage (default) or the older two / three launches per stage
         self.stage_fwd, self.stage_bwd = _STAGE_FWD, _STAGE_BWD
         self.keep_superseded_workspaces = False               # set once a hipGraph holds pointers into the workspace
@@ -151,11 +157,24 @@ class NativeHead:
              torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------ forward
-    @staticmethod
-    def fill_masks(masks):
+    def fill_masks(self, masks, step_dev=None):
         """Dropout masks of one step (GRU inter-layer | fusion MLP, keep probability 0.7, pre-scaled) into `masks`
-        f32[2*B*32, 256]: two launches that depend on nothing, so a pipelined caller can issue them ahead of the head."""
-        return masks.bernoulli_(0.7).div_(0.7)
+        f32[2*B*32, 256]: one launch that depends on nothing, so a pipelined caller can issue it ahead of the head.
+        step_dev: device int64[1] holding the step number (for launches that are captured and replayed: the host sets it
+        with next_mask_step before every replay); default: this head's own step count -- under capture its device word."""
+        if step_dev is None and torch.cuda.is_current_stream_capturing():
+            step_dev = self.mask_step_dev
+        step = 0
+        if step_dev is None:
+            step, self.mask_step = self.mask_step, self.mask_step + 1
+        call("eventad_dropout_masks", ptr(masks), masks.numel(), 0.7, self.mask_seed, step, ptr(step_dev),
+             torch.cuda.current_stream().cuda_stream)
+        return masks
+
+    def next_mask_step(self, step_dev=None):
+        """Before replaying a graph that holds a captured fill_masks: hand it the next step number (on the current stream)."""
+        (self.mask_step_dev if step_dev is None else step_dev).fill_(self.mask_step)
+        self.mask_step += 1
 
     def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train, lean=False, masks=None):
         """feats f32[B,2,31,64] (ROI features), bbox f32[M,6], bbox_batch i64[M], labels f32[M] or None.

@@ -82,19 +82,16 @@ class TrainStep:
         self.nh.keep_superseded_workspaces = True
 
     def snapshot(self):
-        """Head weights + optimiser state (flat buffers, ~14 MB) and the device's random generator state (dropout masks),
-        e.g. to undo warm-up steps."""
+        """Head weights + optimiser state (flat buffers, ~14 MB) and the dropout-mask step count, e.g. to undo warm-up steps."""
         nh = self.nh
-        return [t.clone() for t in (nh.flat, nh.exp_avg, nh.exp_avg_sq, nh.opt_state)] + [torch.cuda.get_rng_state(nh.flat.device)]
+        return [t.clone() for t in (nh.flat, nh.exp_avg, nh.exp_avg_sq, nh.opt_state)] + [nh.mask_step]
 
     def restore(self, snap):
-        """Not inside a graph capture (the generator state is set from the host)."""
         nh = self.nh
         for dst, src in zip((nh.flat, nh.exp_avg, nh.exp_avg_sq, nh.opt_state), snap):
             dst.copy_(src)
         if len(snap) > 4:
-            torch.cuda.synchronize(nh.flat.device)
-            torch.cuda.set_rng_state(snap[4], nh.flat.device)
+            nh.mask_step = snap[4]
 
     # -------------------------------------------------------------------- eager
     def step(self, data, labels=None):
@@ -106,8 +103,8 @@ class TrainStep:
     # ---- hipGraph: the whole step (backbone + ROI + head fwd/bwd + all-reduce + clip/AdamW) has no host sync, so it
     # can be captured once and replayed.  The captured buffers are static: `data` itself is the graph's input -- copy
     # each new batch of the same shapes INTO it (TrainStep.load_into(data, batch)) on the replaying stream before replay().
-    # Capturing runs warm-up steps and then restores weights, optimiser state and the random generator: it has no side
-    # effect on the model or on the dropout masks of the steps that follow.
+    # Capturing runs warm-up steps and then restores weights, optimiser state and the dropout-mask step count: it has no
+    # side effect on the model or on the masks of the steps that follow.
     def capture(self, data, labels=None, warmup=3):
         body = lambda: self.step(data, labels)
         snap = self.snapshot()                                 # the warm-up steps are real steps: undone below, so that
@@ -129,6 +126,8 @@ class TrainStep:
         return self.graph
 
     def replay(self):
+        if self.model.training:
+            self.nh.next_mask_step()                           # the captured mask draw reads its step number from the device
         self.graph.replay()
         return self._g_loss, self._g_norm
 
@@ -253,7 +252,7 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._pin_workspaces()
-        d["gb"], d["gh"], d["feats"], d["out"] = [], [], [], []
+        d["gb"], d["gh"], d["feats"], d["out"], d["mask_step"] = [], [], [], [], []
         native = getattr(self.model.dagr_model.backbone, "_native", None)
 
         def add_chain():
@@ -270,13 +269,15 @@ class TrainStep:
                 gb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 # the step's dropout masks depend on nothing: they are drawn at the end of the chain's backbone graph, off the
                 # head's chain of dependent launches
-                masks = None
+                masks = step_dev = None
                 if self.model.training:
                     masks = torch.empty((2 * in_h[c].num_graphs * 32, 256), device=in_h[c].bbox.device)
+                    step_dev = torch.zeros(1, dtype=torch.int64, device=masks.device)   # set before each replay (_issue_backbone)
+                d["mask_step"].append(step_dev)
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     feats = self.model.extract_features(in_b[c], frames=(1,))
                     if masks is not None:
-                        self.nh.fill_masks(masks)
+                        self.nh.fill_masks(masks, step_dev)
                 # the head's loss and gradient norm live in the ONE head workspace every chain shares: each head graph ends
                 # by copying them into two floats of its own, so a step's results stay readable until the chain's next turn
                 res = torch.zeros(2, device=in_h[c].bbox.device)
@@ -334,7 +335,7 @@ class TrainStep:
             sg.wait_stream(main)
         sh.wait_stream(main)
         with torch.cuda.stream(sgs[0]):                        # the first batch enters the pipeline
-            d["gb"][0].replay()
+            self._replay_backbone(d, 0)
             d["ev_b"][0].record(sgs[0])
         self._g_loss, self._g_norm = d["out"][0]
         return d["gb"], d["gh"]
@@ -399,8 +400,14 @@ class TrainStep:
             if d["in_h_id"][c] != d["in_b_id"][c]:
                 d["in_h"][c].copy_from(d["in_b"][c])
                 d["in_h_id"][c] = d["in_b_id"][c]
-            d["gb"][c].replay()
+            self._replay_backbone(d, c)
             d["ev_b"][c].record(sg)
+
+    def _replay_backbone(self, d, c):
+        """Backbone graph of chain c on the current stream; it ends with the mask draw of the step it belongs to."""
+        if d["mask_step"][c] is not None:
+            self.nh.next_mask_step(d["mask_step"][c])
+        d["gb"][c].replay()
 
     def replay_dual(self, next_batch=None, join=True):
         """One pipelined step: head update of the batch loaded by the previous call (or capture_dual) || backbone of

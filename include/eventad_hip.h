@@ -312,6 +312,13 @@ int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_a
                        double beta2, double eps, double weight_decay, double max_norm, float* partial, float* state,
                        void* stream);
 
+/* Dropout masks of one training step: out f32[n] (16-byte aligned) = 1/keep_prob with probability keep_prob, else 0
+ * (the inter-layer dropout of nn.GRU and nn.Dropout of the fusion MLP, models/EventAD.py:26,86; the reference draws them
+ * from torch's global generator).  Counter-based: value i depends on (seed, step, i) only; step is read from step_dev (a
+ * device word the caller sets before launching or replaying) when that is non-null, so a captured launch serves every step. */
+int eventad_dropout_masks(float* out, int64_t n, double keep_prob, int64_t seed, int64_t step, const int64_t* step_dev,
+                          void* stream);
+
 /* ---- (G) CNN feature branch: replaces HookModule.forward over torchvision resnet50 ---------------- */
 /* (reference src/dagr/model/networks/net_img.py:122-134, net.py:41-49).  NHWC fp32 implicit-GEMM convolution
  * on fp32 MFMA: in f32[B,IH,IW,Cin] (Cin % 4 == 0), w f32[KH*KW*Cin, Cout] with k = (kh*KW+kw)*Cin+ci

@@ -293,3 +293,34 @@ def test_optimiser_skips_non_finite_and_all_zero_gradients():
     nh.optimizer_step()
     torch.cuda.synchronize()
     assert float(nh.opt_state[0]) == 2.0 and float(nh.opt_state[6]) == 0.0 and not torch.equal(nh.flat, before[0])
+
+
+def test_dropout_masks_are_a_function_of_seed_step_and_index():
+    """eventad_dropout_masks: values in {0, 1/keep}, keep rate as asked, a step's masks are reproducible whether the step
+    number comes as an argument or from a device word, different steps and seeds give different masks, and a prefix of a
+    longer draw equals the shorter draw (value i depends on i only)."""
+    import ctypes
+    from eventad_amd._lib import call, ptr
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    n = 2 * 8 * 32 * 256
+
+    def draw(n, seed, step, step_dev=None):
+        out = torch.full((n + 4,), -1.0, device=dev)
+        call("eventad_dropout_masks", ptr(out), n, 0.7, seed, step, ptr(step_dev), st)
+        assert bool((out[n:] == -1).all())
+        return out[:n]
+
+    a = draw(n, 42, 5)
+    vals = torch.unique(a)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.7) < 1e-6
+    assert abs(float((a > 0).float().mean()) - 0.7) < 5e-3
+    assert torch.equal(a, draw(n, 42, 5))
+    assert torch.equal(a, draw(n, 42, 0, torch.tensor([5], dtype=torch.int64, device=dev)))
+    assert torch.equal(a[:1001], draw(1001, 42, 5))
+    for other in (draw(n, 42, 6), draw(n, 43, 5)):
+        agree = float((other == a).float().mean())
+        assert abs(agree - (0.7 * 0.7 + 0.3 * 0.3)) < 5e-3      # independent masks agree on p^2 + (1-p)^2 of the entries
+    # neighbouring entries are uncorrelated
+    k = (a > 0).float()
+    assert abs(float((k[:-1] * k[1:]).mean()) - 0.49) < 5e-3
