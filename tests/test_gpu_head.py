@@ -163,7 +163,7 @@ def test_launch_forms_agree_with_dropout_active():
     out = {}
     for form, (f, b) in FORMS.items():
         nh.stage_fwd, nh.stage_bwd = f, b
-        torch.manual_seed(123)
+        nh.mask_step = 123                                        # the masks are a function of (seed, step): the same in every form
         loss, logits, valid, _ = nh.forward(feats, data.bbox, data.bbox_batch, labels, 8, 256, 256, True)
         nh.backward()
         torch.cuda.synchronize()
