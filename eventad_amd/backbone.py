@@ -58,6 +58,8 @@ class NativeBackbone:
         self.fused_blend_pool = os.environ.get("EVENTAD_FUSED_BLEND_POOL", "1") != "0"
         self._tail_arena_clean = False
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
+        with torch.cuda.device(self.device):
+            call("eventad_spiral_prepare", self.geom.radius_px)      # spiral tables on this GPU, before any capture
         self.load_weights(state_dict)
 
     # ------------------------------------------------------------------ weights

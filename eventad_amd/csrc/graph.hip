@@ -16,6 +16,9 @@
 //      numbering, so the layer-1 neighbour gathers that follow hit nearby rows.
 #include "common.h"
 #include <mutex>
+#include <vector>
+#include <algorithm>
+#include <cstdlib>
 #include <stdio.h>
 
 // ------------------------------------------------------------------ spiral (reference spiral.h)
@@ -93,37 +96,102 @@ __global__ void k_fill_edges(const int32_t* __restrict__ batch, const int32_t* _
     }
 }
 
-static int16_t* g_spiral_dev = nullptr;     // small cached device copy of the spiral table
-static int g_spiral_radius = -1;
-// The same table in constant memory: the spiral step index is wave-uniform, so reads through this
-// symbol are scalar loads (s_load through the constant cache) instead of 2 vector loads per step.
+// Spiral tables on the device.  Radii 0..SPIRAL_MAX_R live back to back in constant memory (table of radius r starts at
+// entry spiral_base(r)): written once per GPU, never changed afterwards, so models with different radii -- and graphs
+// captured for them -- can coexist in one process.  The spiral step index is wave-uniform in the per-event walks, so reads
+// through these symbols are scalar loads.  Larger radii (the generic kernels only) get a device table per (GPU, radius),
+// kept until the process ends.
 #define SPIRAL_MAX_R 13
-__constant__ int16_t c_spiral[2 * (2 * SPIRAL_MAX_R + 1) * (2 * SPIRAL_MAX_R + 1)];
-__constant__ int16_t c_stepof[(2 * SPIRAL_MAX_R + 1) * (2 * SPIRAL_MAX_R + 1)];   // inverse: (dy+R)*D + (dx+R) -> spiral step
+#define SPIRAL_TOTAL 4495                    /* sum over r = 0..13 of (2r+1)^2 */
+__constant__ int16_t c_spiral[2 * SPIRAL_TOTAL];
+__constant__ int16_t c_stepof[SPIRAL_TOTAL];   // inverse: (dy+R)*D + (dx+R) -> spiral step
+static inline int spiral_base(int r) { return r * (2 * r - 1) * (2 * r + 1) / 3; }     // sum over k < r of (2k+1)^2
 
-static int ensure_spiral(int radius, hipStream_t st, int* steps_out) {
-    int steps = (2 * radius + 1) * (2 * radius + 1);
-    if (radius != g_spiral_radius) {
-        int16_t* host = (int16_t*)malloc(sizeof(int16_t) * 2 * steps);
-        eventad_spiral_offsets(radius, host);
-        if (g_spiral_dev) hipFree(g_spiral_dev);
-        if (hipMalloc(&g_spiral_dev, sizeof(int16_t) * 2 * steps) != hipSuccess) { free(host); return -2; }
-        hipMemcpyAsync(g_spiral_dev, host, sizeof(int16_t) * 2 * steps, hipMemcpyHostToDevice, st);
-        if (radius <= SPIRAL_MAX_R) {
-            hipMemcpyToSymbolAsync(HIP_SYMBOL(c_spiral), host, sizeof(int16_t) * 2 * steps, 0, hipMemcpyHostToDevice, st);
-            int D = 2 * radius + 1;
-            int16_t* inv = (int16_t*)malloc(sizeof(int16_t) * steps);
-            for (int i = 0; i < steps; ++i) inv[(host[2 * i + 1] + radius) * D + host[2 * i] + radius] = (int16_t)i;
-            hipMemcpyToSymbolAsync(HIP_SYMBOL(c_stepof), inv, sizeof(int16_t) * steps, 0, hipMemcpyHostToDevice, st);
-            hipStreamSynchronize(st);
-            free(inv);
-        }
-        hipStreamSynchronize(st);
-        free(host);
-        g_spiral_radius = radius;
-    }
+#define EVAD_MAX_DEVICES 64
+static std::mutex g_spiral_mutex;
+static bool g_spiral_const_ready[EVAD_MAX_DEVICES];
+// Ring bands of a spiral for the row-major wave-per-pixel search (k_build_ell_pixr): consecutive whole rings with at most
+// BAND_CAP pixels per band; inside a band the pixels come in row-major order (dy, then dx), each as
+// (dx + 128) | (dy + 128) << 8 | spiral step << 16.
+#define BAND_CAP 256
+#define BAND_MAX 8
+struct BandPasses { int n; int off[BAND_MAX], cnt[BAND_MAX], step0[BAND_MAX]; };
+struct SpiralDev { int dev, radius; int16_t* table; uint32_t* band; BandPasses passes; };
+static std::vector<SpiralDev*> g_spiral_tables;
+
+// Tables for `radius` on the current device; *entry_out (nullable) = the radius' own device tables (spiral [steps][2], ring
+// bands).  The first call for a GPU (and for a new radius) allocates and copies synchronously: make it outside any stream
+// capture (eventad_spiral_prepare); later calls only look the tables up.
+static int ensure_spiral(int radius, int* steps_out, const SpiralDev** entry_out) {
+    const int steps = (2 * radius + 1) * (2 * radius + 1);
     *steps_out = steps;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EVAD_MAX_DEVICES) return -2;
+    std::lock_guard<std::mutex> lock(g_spiral_mutex);
+    if (!g_spiral_const_ready[dev]) {
+        std::vector<int16_t> all(2 * SPIRAL_TOTAL), inv(SPIRAL_TOTAL);
+        for (int r = 0; r <= SPIRAL_MAX_R; ++r) {
+            const int b0 = spiral_base(r), D = 2 * r + 1, n = D * D;
+            int16_t* t = all.data() + 2 * b0;
+            eventad_spiral_offsets(r, t);
+            for (int i = 0; i < n; ++i) inv[b0 + (t[2 * i + 1] + r) * D + t[2 * i] + r] = (int16_t)i;
+        }
+        if (hipMemcpyToSymbol(HIP_SYMBOL(c_spiral), all.data(), sizeof(int16_t) * all.size()) != hipSuccess ||
+            hipMemcpyToSymbol(HIP_SYMBOL(c_stepof), inv.data(), sizeof(int16_t) * inv.size()) != hipSuccess) {
+            (void)hipGetLastError();
+            return -2;
+        }
+        g_spiral_const_ready[dev] = true;
+    }
+    if (!entry_out) return 0;
+    for (const SpiralDev* e : g_spiral_tables)
+        if (e->dev == dev && e->radius == radius) { *entry_out = e; return 0; }
+    std::vector<int16_t> host(2 * (size_t)steps);
+    eventad_spiral_offsets(radius, host.data());
+    SpiralDev* e = new SpiralDev{dev, radius, nullptr, nullptr, {}};
+    if (hipMalloc(&e->table, sizeof(int16_t) * host.size()) != hipSuccess ||
+        hipMemcpy(e->table, host.data(), sizeof(int16_t) * host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError(); delete e;
+        return -2;
+    }
+    if (radius <= SPIRAL_MAX_R) {                            // ring bands (radius <= 13: at most 4)
+        const int D = 2 * radius + 1;
+        std::vector<int> stepof((size_t)D * D);
+        for (int i = 0; i < steps; ++i) stepof[(size_t)(host[2 * i + 1] + radius) * D + host[2 * i] + radius] = i;
+        std::vector<uint32_t> band;
+        BandPasses& P = e->passes;
+        P.n = 0;
+        for (int r0 = 0; r0 <= radius && P.n < BAND_MAX;) {
+            int r1 = r0;
+            const int inner = r0 == 0 ? 0 : (2 * r0 - 1) * (2 * r0 - 1);
+            while (r1 + 1 <= radius && (2 * r1 + 3) * (2 * r1 + 3) - inner <= BAND_CAP) ++r1;
+            P.off[P.n] = (int)band.size(); P.step0[P.n] = inner;
+            for (int dy = -r1; dy <= r1; ++dy)
+                for (int dx = -r1; dx <= r1; ++dx) {
+                    const int ring = std::max(std::abs(dx), std::abs(dy));
+                    if (ring < r0) continue;
+                    band.push_back((uint32_t)(dx + 128) | (uint32_t)(dy + 128) << 8 | (uint32_t)stepof[(size_t)(dy + radius) * D + dx + radius] << 16);
+                }
+            P.cnt[P.n] = (int)band.size() - P.off[P.n];
+            if (P.cnt[P.n] > BAND_CAP) { P.n = 0; break; }     // (a single ring larger than a band: radius > 32, not reached)
+            ++P.n;
+            r0 = r1 + 1;
+        }
+        if (P.n > 0 && (hipMalloc(&e->band, sizeof(uint32_t) * band.size()) != hipSuccess ||
+                        hipMemcpy(e->band, band.data(), sizeof(uint32_t) * band.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+            (void)hipGetLastError(); hipFree(e->table); delete e;
+            return -2;
+        }
+    }
+    g_spiral_tables.push_back(e);
+    *entry_out = e;
     return 0;
+}
+
+extern "C" int eventad_spiral_prepare(int radius) {
+    if (radius < 0 || radius > 127) return EVAD_ERR_ARG;
+    int steps; const SpiralDev* e = nullptr;
+    return ensure_spiral(radius, &steps, &e);
 }
 
 extern "C" int eventad_insert_in_queue(const int32_t* indices, const int32_t* unique_coords,
@@ -152,10 +220,10 @@ extern "C" int eventad_fill_edges(const int32_t* batch, const int32_t* pos, cons
         radius < 0 || B <= 0 || Q <= 0 || H <= 0 || W <= 0 || N < 0 || K < (int64_t)N * max_num_neighbors)
         return EVAD_ERR_ARG;
     if (N == 0) return EVAD_OK;
-    int steps;
-    if (ensure_spiral((int)radius, (hipStream_t)stream, &steps)) return -2;
+    int steps; const SpiralDev* sp = nullptr;
+    if (ensure_spiral((int)radius, &steps, &sp)) return -2;
     hipLaunchKernelGGL(k_fill_edges, dim3(evad_blocks(N, 256)), dim3(256), 0, (hipStream_t)stream,
-                       batch, pos, all_timestamps, indices, event_queue, g_spiral_dev, edges, Q, H, W, N, K,
+                       batch, pos, all_timestamps, indices, event_queue, sp->table, edges, Q, H, W, N, K,
                        steps, delta_t_us, max_num_neighbors, min_index);
     return evad_last_error();
 }
@@ -569,7 +637,6 @@ extern "C" int eventad_sort_events(const float* pos, const int64_t* batch, const
 #define EVAD_STATIC_OFF_SID    (EVAD_STATIC_OFF_SCAN + ((EVAD_STATIC_SCAN_WORDS + 63) / 64) * 64)
 #define EVAD_STATIC_WORDS      (EVAD_STATIC_OFF_SID + EVAD_STATIC_MAX_EVENTS)
 static __device__ __align__(256) uint32_t scratch[EVAD_STATIC_WORDS];
-#define EVAD_MAX_DEVICES 64
 static uint32_t* g_scratch_ptr[EVAD_MAX_DEVICES];        // device address of `scratch` per GPU (the symbol itself is no address)
 static std::mutex g_scratch_mutex;
 
@@ -666,12 +733,14 @@ __global__ __launch_bounds__(256) void k_build_ell(const int* __restrict__ sid, 
 template <bool MARK, bool BY_RANK>
 __global__ __launch_bounds__(ELL_TILE) void k_build_ell_reg(const int2* __restrict__ ev2,
                                                        const int* __restrict__ key_s, const unsigned* __restrict__ start,
-                                                       const unsigned* flags_in, int N, int W, int H, int steps, int Q,
+                                                       const unsigned* flags_in, int N, int W, int H, int steps, int sp0, int Q,
                                                        int dt_max, int* __restrict__ ell_src, uint16_t* __restrict__ ell_step,
                                                        int* __restrict__ deg, const int* __restrict__ node_slot,
                                                        const int* __restrict__ node_vox, unsigned* __restrict__ bitmap,
-                                                       unsigned* flags) {
+                                                       unsigned* flags, int only_not_monotone) {
     constexpr int MAXNB = 16;
+    // only_not_monotone: this launch stands behind a kernel that leaves batches with non-monotone timestamps alone
+    if (only_not_monotone && !(*flags_in & EVAD_FLAG_T_NOT_MONOTONE)) return;
     __shared__ int s_perm[ELL_TILE];
     __shared__ int s_cnt[64];
     __shared__ int s_mm[2];
@@ -718,7 +787,7 @@ __global__ __launch_bounds__(ELL_TILE) void k_build_ell_reg(const int2* __restri
     nb[0] = r;
     int nn = 1;
     for (int i = 0; i < steps && nn < MAXNB; ++i) {
-        int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+        int xn = x + c_spiral[2 * (sp0 + i)], yn = y + c_spiral[2 * (sp0 + i) + 1];
         if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
         int p = plane_base + xn + W * yn;
         int st = (int)start[p], en = (int)start[p + 1];
@@ -765,11 +834,11 @@ __global__ __launch_bounds__(ELL_TILE) void k_build_ell_reg(const int2* __restri
 #define RS_UNR 8
 template <int MAXNB>
 __device__ __forceinline__ int ell_exact_walk(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int me, int ts,
-                                              int x, int y, int plane_base, int W, int H, int steps, int Q, int dt_max,
+                                              int x, int y, int plane_base, int W, int H, int steps, int sp0, int Q, int dt_max,
                                               bool monotone, int (&nb)[MAXNB], int (&stp)[MAXNB]) {
     int nn = 1;
     for (int i = 0; i < steps && nn < MAXNB; ++i) {
-        int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
+        int xn = x + c_spiral[2 * (sp0 + i)], yn = y + c_spiral[2 * (sp0 + i) + 1];
         if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
         int p = plane_base + xn + W * yn;
         int st = (int)start[p], en = (int)start[p + 1];
@@ -792,7 +861,7 @@ __device__ __forceinline__ int ell_exact_walk(const int2* __restrict__ ev2, cons
 template <int R, bool MARK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_build_ell_rowscan(const int2* __restrict__ ev2, const int* __restrict__ key_s,
                                                            const unsigned* __restrict__ start, const unsigned* flags_in, int N,
-                                                           int W, int H, int steps, int Q, int dt_max, int* __restrict__ ell_src,
+                                                           int W, int H, int steps, int sp0, int Q, int dt_max, int* __restrict__ ell_src,
                                                            uint16_t* __restrict__ ell_step, int* __restrict__ deg,
                                                            const int* __restrict__ node_slot, const int* __restrict__ node_vox,
                                                            unsigned* __restrict__ bitmap, unsigned* flags) {
@@ -801,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     __shared__ unsigned short s_stepof[D * D];
     __shared__ signed char s_dyi[D * D];
     const int tid = threadIdx.x;
-    if (tid < D * D) { s_stepof[tid] = (unsigned short)c_stepof[tid]; s_dyi[tid] = (signed char)(c_spiral[2 * tid + 1] + R); }
+    if (tid < D * D) { s_stepof[tid] = (unsigned short)c_stepof[sp0 + tid]; s_dyi[tid] = (signed char)(c_spiral[2 * (sp0 + tid) + 1] + R); }
     __syncthreads();
     const int r = blockIdx.x * 256 + tid;
     const bool active = r < N;
@@ -885,7 +954,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             nn = 1 + min(n, MAXNB - 1);
         }
     }
-    if (exact && active) nn = ell_exact_walk<MAXNB>(ev2, start, me, ts, x, y, plane_base, W, H, steps, Q, dt_max, monotone, nb, stp);
+    if (exact && active) nn = ell_exact_walk<MAXNB>(ev2, start, me, ts, x, y, plane_base, W, H, steps, sp0, Q, dt_max, monotone, nb, stp);
     if (active) {
         int4* rp = (int4*)(ell_src + (size_t)r * MAXNB);
         rp[0] = make_int4(nb[0], nb[1], nb[2], nb[3]); rp[1] = make_int4(nb[4], nb[5], nb[6], nb[7]);
@@ -944,7 +1013,7 @@ __device__ __forceinline__ void pix_bounds(const unsigned* __restrict__ start, i
 
 template <int GS, bool INT_CMP, bool PRE>
 __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int N, int W, int H,
-                                             int steps, int Q, int dt_max, int x, int y, int plane_base, int i0, int md,
+                                             int steps, int sp0, int Q, int dt_max, int x, int y, int plane_base, int i0, int md,
                                              int* my_src, unsigned short* my_stp, const int2* my_dest, int* my_cnt, int st, int en) {
     constexpr int MAXNB = 16, NG = 64 / GS;
     const int lane = threadIdx.x & 63, g = lane / GS, l = lane % GS;
@@ -952,7 +1021,7 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
     const int i = i0 + l;
     if (!PRE) {                                              // (the first pass gets its bounds from the caller, loaded ahead)
         const int ii = min(i, steps - 1);
-        pix_bounds(start, x, y, plane_base, W, H, c_spiral[2 * ii], c_spiral[2 * ii + 1], i < steps, st, en);
+        pix_bounds(start, x, y, plane_base, W, H, c_spiral[2 * (sp0 + ii)], c_spiral[2 * (sp0 + ii) + 1], i < steps, st, en);
     }
     const int lo = max(st, en - Q);                          // the FIFO keeps only the newest Q ids
     const int len = en - lo, lenr = min(len, PIX_DEPTH), ninv = PIX_DEPTH - lenr;
@@ -1048,6 +1117,39 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
     PIX_LDS_ORDER();
 }
 
+// Batches whose timestamps are not monotone in the id (rare): plain per-event walk over the events [ds, de) of the pixel
+// (x, y), one event per lane, rows written slot by slot; the reference's `continue` on a too-old entry matters here.
+__device__ __forceinline__ void pix_walk_events(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int ds, int de, int x,
+                                                int y, int plane_base, int W, int H, int steps, int sp0, int Q, int dt_max,
+                                                int* __restrict__ ell_src, uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
+    constexpr int MAXNB = 16;
+    const int lane = threadIdx.x & 63;
+    for (int r = ds + lane; r < de; r += 64) {
+        const int2 mine = ev2[r];
+        int* orow = ell_src + (size_t)r * MAXNB;
+        uint16_t* srow = ell_step + (size_t)r * MAXNB;
+        for (int e = 1; e < MAXNB; ++e) { orow[e] = 0; srow[e] = 0; }
+        orow[0] = r; srow[0] = 0;
+        int nn = 1;
+        for (int i = 0; i < steps && nn < MAXNB; ++i) {
+            const int xn = x + c_spiral[2 * (sp0 + i)], yn = y + c_spiral[2 * (sp0 + i) + 1];
+            if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
+            const int q = plane_base + xn + W * yn;
+            const int st = (int)start[q], en = (int)start[q + 1];
+            const int lo = max(st, en - Q);
+            for (int s = en - 1; s >= lo; --s) {
+                const int2 c = ev2[s];
+                if (mine.x > c.x) {
+                    if ((float)(mine.y - c.y) > (float)dt_max) continue;
+                    orow[nn] = s; srow[nn] = (uint16_t)i;
+                    if (++nn >= MAXNB) break;
+                }
+            }
+        }
+        deg[r] = nn;
+    }
+}
+
 // Workgroup = 4 waves on a strip of PIX_STRIP pixels of one sensor row: at any moment the four waves work on four adjacent
 // pixels, whose 7x7 (...) neighbourhoods are nearly the same cache lines, so most of a wave's gathers hit the CU's L1 (one
 // wave per workgroup, dealt pixel by pixel over all CUs, missed it on nearly every line and waited for L2).  Strips are
@@ -1056,7 +1158,7 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
 template <int GS1, bool INT_CMP>
 __global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
                                                       const unsigned* __restrict__ flags_in, int N, int n_strips, int W, int H, int steps,
-                                                      int Q, int dt_max, int* __restrict__ ell_src,
+                                                      int sp0, int Q, int dt_max, int* __restrict__ ell_src,
                                                       uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
     constexpr int MAXNB = 16;
     static_assert(PIX_CHUNK == 16, "one int4 per lane covers the chunk's rows");
@@ -1076,7 +1178,7 @@ __global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict
     // the first pass's spiral offsets are the same for every pixel and are read once, and the bounds a pixel needs first
     // (its own segment, its neighbours') are requested one pixel ahead.
     const int first = min(GS1, steps), l1 = lane % GS1, ii1 = min(l1, steps - 1);
-    const int sdx = c_spiral[2 * ii1], sdy = c_spiral[2 * ii1 + 1];
+    const int sdx = c_spiral[2 * (sp0 + ii1)], sdy = c_spiral[2 * (sp0 + ii1) + 1];
     const int xend = min(x0 + PIX_STRIP, W);
     int x = x0 + wv;
     if (x >= xend) return;
@@ -1091,33 +1193,7 @@ __global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict
             own_n = *(const PixBounds*)(start + plane_base + x + 4 + W * y);
         }
         if (de <= ds) continue;
-        if (walk) {                                          // rare: plain per-event walk, rows written slot by slot
-            for (int r = ds + lane; r < de; r += 64) {
-                const int2 mine = ev2[r];
-                int* orow = ell_src + (size_t)r * MAXNB;
-                uint16_t* srow = ell_step + (size_t)r * MAXNB;
-                for (int e = 1; e < MAXNB; ++e) { orow[e] = 0; srow[e] = 0; }
-                orow[0] = r; srow[0] = 0;
-                int nn = 1;
-                for (int i = 0; i < steps && nn < MAXNB; ++i) {
-                    const int xn = x + c_spiral[2 * i], yn = y + c_spiral[2 * i + 1];
-                    if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
-                    const int q = plane_base + xn + W * yn;
-                    const int st = (int)start[q], en = (int)start[q + 1];
-                    const int lo = max(st, en - Q);
-                    for (int s = en - 1; s >= lo; --s) {
-                        const int2 c = ev2[s];
-                        if (mine.x > c.x) {
-                            if ((float)(mine.y - c.y) > (float)dt_max) continue;
-                            orow[nn] = s; srow[nn] = (uint16_t)i;
-                            if (++nn >= MAXNB) break;
-                        }
-                    }
-                }
-                deg[r] = nn;
-            }
-            continue;
-        }
+        if (walk) { pix_walk_events(ev2, start, ds, de, x, y, plane_base, W, H, steps, sp0, Q, dt_max, ell_src, ell_step, deg); continue; }
         for (int d0 = ds; d0 < de; d0 += PIX_CHUNK) {        // the pixel's destination events, PIX_CHUNK at a time
             const int md = min(PIX_CHUNK, de - d0);
             if (lane < PIX_CHUNK) {
@@ -1129,16 +1205,259 @@ __global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict
             PIX_LDS_ORDER();
             if (lane < PIX_CHUNK) my_src[lane * MAXNB] = d0 + lane;
             PIX_LDS_ORDER();
-            ell_pix_pass<GS1, INT_CMP, true>(ev2, start, N, W, H, first, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt, st1, en1);
+            ell_pix_pass<GS1, INT_CMP, true>(ev2, start, N, W, H, first, sp0, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt, st1, en1);
             for (int i0 = first; i0 < steps; i0 += 64) {
                 if (!__ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB)) break;
-                ell_pix_pass<64, INT_CMP, false>(ev2, start, N, W, H, steps, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt, 0, 0);
+                ell_pix_pass<64, INT_CMP, false>(ev2, start, N, W, H, steps, sp0, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt, 0, 0);
             }
             if (lane < md * 4) ((int4*)(ell_src + (size_t)d0 * MAXNB))[lane] = ((const int4*)my_src)[lane];
             if (lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[lane] = ((const uint4*)my_stp)[lane];
             if (lane < md) deg[d0 + lane] = my_cnt[lane];
             PIX_LDS_ORDER();
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-per-pixel search for LARGE windows at LOW density (the 1280x720 geometry: radius 13 = 729 spiral steps, half an event
+// per pixel).  With lanes = consecutive spiral steps, the 64 neighbour pixels of a pass lie on ring sides: the vertical
+// sides are 64 different cache lines, for the bounds and again for the entries, so the kernel is bound by the number of
+// line requests (holding four spiral steps per lane, i.e. four times the loads in flight, made it slower: 6.7 against
+// 5.0 ms on 4 M events), and more than half of the pixels a wave visits are empty.
+// Here the lanes of a wave take the pixels of a RING BAND (whole rings, at most 256 pixels: rings 0..7, 8..10, 11..12, 13
+// at radius 13) in ROW-MAJOR order, PR_SPL pixels per lane.  The bounds of a sensor row's pixels are consecutive words and
+// their FIFO entries consecutive records of the pixel-sorted array, so a wave-wide load touches a handful of lines
+// instead of one per lane.  The price is that lane order is no longer spiral order: per event the lanes drop their
+// source counts into a per-wave LDS table indexed by spiral step, the wave scans that table (four steps per lane) and
+// every pixel picks up the exclusive sum of its step -- the slot where its sources go, newest first, until 16 are taken.
+// Most events are complete after the first band (225 pixels); only the early events of a clip go on.  Each wave first
+// looks at the own segments of its strip's 16 pixels (one load) and takes every fourth NON-EMPTY pixel; neighbour bounds
+// are requested, one pixel ahead, only for pixels that hold events.  One event at a time per wave (a pixel holds 1.3 on
+// average).  A lane keeps the PR_DEPTH newest entries of a pixel in registers; deeper pixels are read on from memory.
+#define PR_SPL 4
+#define PR_DEPTH 4
+#ifndef PR_WAVES
+#define PR_WAVES 4
+#endif
+// bounds of the PR_SPL pixels of this lane in a band: entry idx = k * 64 + lane of the band's row-major list
+__device__ __forceinline__ void pixr_bounds(const unsigned* __restrict__ start, int x, int y, int plane_base, int W, int H,
+                                            const unsigned (&ent)[PR_SPL], int (&st)[PR_SPL], int (&en)[PR_SPL]) {
+#pragma unroll
+    for (int k = 0; k < PR_SPL; ++k) {
+        const bool live = ent[k] != 0xffffffffu;
+        pix_bounds(start, x, y, plane_base, W, H, (int)(ent[k] & 255u) - 128, (int)((ent[k] >> 8) & 255u) - 128, live, st[k], en[k]);
+    }
+}
+
+template <bool INT_CMP>
+__device__ __forceinline__ void ell_pixr_pass(const int2* __restrict__ ev2, int N, int Q, int dt_max, int step0,
+                                              const unsigned (&ent)[PR_SPL], const int (&st)[PR_SPL], const int (&en)[PR_SPL],
+                                              int* my_src, unsigned short* my_stp, const int2* my_dest, int* my_cnt,
+                                              unsigned* my_nq /* [64] words = 256 step counts */, unsigned* my_pre /* [64] */) {
+    constexpr int MAXNB = 16;
+    const int lane = threadIdx.x & 63;
+    const float fdt = (float)dt_max;
+    int lo[PR_SPL], lenr[PR_SPL], eold[PR_SPL], eid[PR_SPL][PR_DEPTH], et[PR_SPL][PR_DEPTH];
+    bool plain = N >= PR_DEPTH;
+#pragma unroll
+    for (int k = 0; k < PR_SPL; ++k) {
+        lo[k] = max(st[k], en[k] - Q);                       // the FIFO keeps only the newest Q ids
+        lenr[k] = min(en[k] - lo[k], PR_DEPTH);
+        plain = plain && (en[k] >= PR_DEPTH || en[k] == lo[k]);
+    }
+    // the PR_DEPTH newest entries end at en - 1: 16-byte loads of two entries each, only the pairs a segment has (an odd
+    // length reads one entry of the neighbouring segment, harmless); only a wave that touches the first PR_DEPTH events of
+    // the whole array clamps every index instead
+    if (__all(plain)) {
+        struct __attribute__((aligned(8))) Piece { int4 v; };
+#pragma unroll
+        for (int k = 0; k < PR_SPL; ++k) {
+            const Piece* top = (const Piece*)(ev2 + (lenr[k] > 0 ? en[k] - PR_DEPTH : 0));
+            int4 r1 = make_int4(0, 0, 0, 0), r0 = make_int4(0, 0, 0, 0);
+            if (lenr[k] > 0) r1 = top[1].v;                  // entries en - 2 (older) and en - 1
+            if (lenr[k] > 2) r0 = top[0].v;                  // entries en - 4 and en - 3
+            eid[k][0] = r1.z; et[k][0] = r1.w; eid[k][1] = r1.x; et[k][1] = r1.y;
+            eid[k][2] = r0.z; et[k][2] = r0.w; eid[k][3] = r0.x; et[k][3] = r0.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PR_SPL; ++k)
+#pragma unroll
+            for (int v = 0; v < PR_DEPTH; ++v) { const int2 c = ev2[min(max(en[k] - 1 - v, lo[k]), max(N - 1, 0))]; eid[k][v] = c.x; et[k][v] = c.y; }
+    }
+#pragma unroll
+    for (int k = 0; k < PR_SPL; ++k) {
+        // padding (entries past the segment's length): older than any event and out of any time window, so it is counted
+        // neither as "not older" nor as a source
+#pragma unroll
+        for (int v = 0; v < PR_DEPTH; ++v) { if (v >= lenr[k]) { eid[k][v] = (int)0x80000000; et[k][v] = -(1 << 30); } }
+        // oldest entry of a deep pixel: if even that one is not older than the event, nothing below the registers is
+        eold[k] = en[k] - lo[k] > PR_DEPTH ? ev2[min(lo[k], N - 1)].x : 0x7fffffff;
+    }
+    my_nq[lane] = 0u;                                        // steps past the band's last one count nothing
+    PIX_LDS_ORDER();
+    unsigned char* nq_b = (unsigned char*)my_nq;
+    const unsigned char* pre_b = (const unsigned char*)my_pre;
+    unsigned long long todo = __ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB);   // bit d: event d still lacks sources
+    while (todo) {
+        const int d = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int base = my_cnt[d];
+        const int2 mine = my_dest[d];
+        const int me = mine.x, ts = mine.y, t_min = ts - dt_max;
+        int nnew[PR_SPL], nq[PR_SPL];
+        unsigned undecided = 0;
+#pragma unroll
+        for (int k = 0; k < PR_SPL; ++k) {
+            int cge = 0, nin = 0;
+#pragma unroll
+            for (int v = 0; v < PR_DEPTH; ++v) {
+                cge += eid[k][v] >= me ? 1 : 0;
+                if (INT_CMP) nin += et[k][v] >= t_min ? 1 : 0;
+                else         nin += (float)(ts - et[k][v]) > fdt ? 0 : 1;
+            }
+            nnew[k] = cge;
+            nq[k] = max(0, nin - cge);
+            if (eold[k] < me && cge + nq[k] == PR_DEPTH) undecided |= 1u << k;          // deep pixel, registers undecided
+        }
+        while (__any(undecided != 0)) {                      // rare: read on from memory, one pixel of a lane at a time
+            if (undecided) {
+                const int k = __ffs((int)undecided) - 1;
+                undecided &= undecided - 1;
+                const int enk = k == 0 ? en[0] : k == 1 ? en[1] : k == 2 ? en[2] : en[3];
+                const int lok = k == 0 ? lo[0] : k == 1 ? lo[1] : k == 2 ? lo[2] : lo[3];
+                int nn = k == 0 ? nnew[0] : k == 1 ? nnew[1] : k == 2 ? nnew[2] : nnew[3];
+                int qq = k == 0 ? nq[0] : k == 1 ? nq[1] : k == 2 ? nq[2] : nq[3];
+                bool stop = false;
+                for (int s = enk - 1 - PR_DEPTH; s >= lok && qq < MAXNB && !stop; s -= 4) {
+                    int2 c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c[u] = ev2[max(s - u, lok)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (stop || s - u < lok || qq >= MAXNB) continue;
+                        if (c[u].x >= me) { ++nn; continue; }
+                        const int dt = ts - c[u].y;
+                        if (INT_CMP ? dt > dt_max : (float)dt > fdt) stop = true; else ++qq;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PR_SPL; ++j) if (j == k) { nnew[j] = nn; nq[j] = qq; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PR_SPL; ++k)
+            if (ent[k] != 0xffffffffu) nq_b[(int)(ent[k] >> 16) - step0] = (unsigned char)nq[k];      // every step of the band is some lane's pixel
+        PIX_LDS_ORDER();
+        // the band's step table in spiral order, four steps per lane: inclusive sum over the wave (DPP row scans, then row
+        // broadcasts), exclusive sums back into the table (clamped to a byte: only sums below 16 matter)
+        const unsigned c4 = my_nq[lane];
+        const int c0 = (int)(c4 & 255u), c1 = (int)((c4 >> 8) & 255u), c2 = (int)((c4 >> 16) & 255u), c3 = (int)(c4 >> 24);
+        const int tot = c0 + c1 + c2 + c3;
+        int inc = tot;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);    // row_bcast15 -> rows 1 and 3
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);    // row_bcast31 -> rows 2 and 3
+        const int e0 = min(inc - tot, 255), e1 = min(e0 + c0, 255), e2 = min(e1 + c1, 255), e3 = min(e2 + c2, 255);
+        my_pre[lane] = (unsigned)e0 | (unsigned)e1 << 8 | (unsigned)e2 << 16 | (unsigned)e3 << 24;
+        PIX_LDS_ORDER();
+#pragma unroll
+        for (int k = 0; k < PR_SPL; ++k) {
+            if (nq[k] > 0 && ent[k] != 0xffffffffu) {
+                const int pos = base + (int)pre_b[(int)(ent[k] >> 16) - step0];
+                const int take = min(nq[k], MAXNB - pos);    // slots left for this pixel's sources
+                for (int u = 0; u < take; ++u) {
+                    my_src[d * MAXNB + pos + u] = en[k] - 1 - nnew[k] - u;
+                    my_stp[d * MAXNB + pos + u] = (unsigned short)(ent[k] >> 16);
+                }
+            }
+        }
+        if (lane == 63) my_cnt[d] = min(MAXNB, base + inc);  // the last lane holds the total
+        PIX_LDS_ORDER();
+    }
+}
+
+template <bool INT_CMP>
+__global__ __launch_bounds__(256, PR_WAVES) void k_build_ell_pixr(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
+                                                       const unsigned* __restrict__ flags_in, const unsigned* __restrict__ band,
+                                                       BandPasses passes, int N, int n_strips, int W, int H, int Q, int dt_max,
+                                                       int* __restrict__ ell_src, uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
+    constexpr int MAXNB = 16;
+    __shared__ int s_src[4][PIX_CHUNK * MAXNB];
+    __shared__ unsigned short s_stp[4][PIX_CHUNK * MAXNB];
+    __shared__ int2 s_dest[4][PIX_CHUNK];
+    __shared__ int s_cnt[4][PIX_CHUNK];
+    __shared__ unsigned s_nq[4][64], s_pre[4][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int* my_src = s_src[wv]; unsigned short* my_stp = s_stp[wv]; int2* my_dest = s_dest[wv]; int* my_cnt = s_cnt[wv];
+    const int per_xcd = (n_strips + 7) >> 3;
+    const int strip = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (strip >= n_strips) return;                           // (no workgroup barrier below: the waves are independent)
+    // (batches whose timestamps are not monotone are left to the per-event walk, launched behind this kernel)
+    if (flags_in[0] & EVAD_FLAG_T_NOT_MONOTONE) return;
+    const int strips_x = (W + PIX_STRIP - 1) / PIX_STRIP;
+    const int row = strip / strips_x, y = row % H, plane_base = (row / H) * W * H, x0 = (strip % strips_x) * PIX_STRIP;
+    const int npx = min(PIX_STRIP, W - x0);
+    // own segments of the strip's pixels: lane l holds the start of pixel x0 + l (lane npx: the end of the last one)
+    const int sb = (int)start[plane_base + W * y + x0 + min(lane, npx)];
+    const int sb1 = __shfl_down(sb, 1, 64);
+    const unsigned occupied = (unsigned)__ballot(lane < npx && sb1 > sb);
+    unsigned mine_px = 0;                                    // this wave's pixels: every fourth non-empty one
+    {
+        int rank = 0;
+        for (unsigned m = occupied; m; m &= m - 1, ++rank) if ((rank & 3) == wv) mine_px |= m & (0u - m);
+    }
+    if (!mine_px) return;
+    // the first band's pixel list is the same for every pixel: read once
+    unsigned ent0[PR_SPL];
+#pragma unroll
+    for (int k = 0; k < PR_SPL; ++k) ent0[k] = k * 64 + lane < passes.cnt[0] ? band[passes.off[0] + k * 64 + lane] : 0xffffffffu;
+    int b = __ffs((int)mine_px) - 1;
+    mine_px &= mine_px - 1;
+    int st_n[PR_SPL], en_n[PR_SPL];                          // first-band bounds of the wave's next pixel, in flight
+    pixr_bounds(start, x0 + b, y, plane_base, W, H, ent0, st_n, en_n);
+    while (true) {
+        const int x = x0 + b;
+        const int ds = __builtin_amdgcn_readlane(sb, b), de = __builtin_amdgcn_readlane(sb, b + 1);
+        unsigned ent[PR_SPL]; int st1[PR_SPL], en1[PR_SPL];
+#pragma unroll
+        for (int k = 0; k < PR_SPL; ++k) { ent[k] = ent0[k]; st1[k] = st_n[k]; en1[k] = en_n[k]; }
+        const int bn = mine_px ? __ffs((int)mine_px) - 1 : -1;
+        mine_px &= mine_px - 1;                              // (0 stays 0)
+        if (bn >= 0) pixr_bounds(start, x0 + bn, y, plane_base, W, H, ent0, st_n, en_n);
+        for (int d0 = ds; d0 < de; d0 += PIX_CHUNK) {        // the pixel's destination events, PIX_CHUNK at a time
+            const int md = min(PIX_CHUNK, de - d0);
+            if (lane < PIX_CHUNK) {
+                my_dest[lane] = ev2[min(d0 + lane, N - 1)];
+                my_cnt[lane] = lane < md ? 1 : MAXNB;        // sources found so far for event d0 + lane (self edge first)
+            }
+            ((int4*)my_src)[lane] = make_int4(0, 0, 0, 0);   // PIX_CHUNK * 16 ints = 64 int4
+            if (lane < PIX_CHUNK * 2) ((uint4*)my_stp)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            PIX_LDS_ORDER();
+            if (lane < PIX_CHUNK) my_src[lane * MAXNB] = d0 + lane;
+            PIX_LDS_ORDER();
+            // band after band (ONE copy of the pass): the first with the bounds requested a pixel ahead, the others -- and the
+            // first again for a pixel's second chunk of 16 events -- with bounds loaded here
+#pragma unroll 1
+            for (int p = 0; p < passes.n; ++p) {
+                if (p > 0 || d0 > ds) {
+                    if (p > 0 && !__ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB)) break;
+#pragma unroll
+                    for (int k = 0; k < PR_SPL; ++k) ent[k] = k * 64 + lane < passes.cnt[p] ? band[passes.off[p] + k * 64 + lane] : 0xffffffffu;
+                    pixr_bounds(start, x, y, plane_base, W, H, ent, st1, en1);
+                }
+                ell_pixr_pass<INT_CMP>(ev2, N, Q, dt_max, passes.step0[p], ent, st1, en1, my_src, my_stp, my_dest, my_cnt, s_nq[wv], s_pre[wv]);
+            }
+            if (lane < md * 4) ((int4*)(ell_src + (size_t)d0 * MAXNB))[lane] = ((const int4*)my_src)[lane];
+            if (lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[lane] = ((const uint4*)my_stp)[lane];
+            if (lane < md) deg[d0 + lane] = my_cnt[lane];
+            PIX_LDS_ORDER();
+        }
+        if (bn < 0) break;
+        b = bn;
     }
 }
 
@@ -1154,18 +1473,19 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
     hipStream_t st = (hipStream_t)stream;
     if (bitmap && !bitmap_prezeroed) evad_zero_async(bitmap, sizeof(uint32_t) * 3 * (size_t)nx * ny * (B + 1), st);
     if (N == 0) return evad_last_error();
-    int steps;
-    if (ensure_spiral(radius_px, st, &steps)) return -2;
-    if (steps > 65535) return EVAD_ERR_ARG;
+    int steps; const SpiralDev* sp = nullptr;
     const bool fast = max_num_neighbors == 16 && ev2 && radius_px <= SPIRAL_MAX_R;
+    if (ensure_spiral(radius_px, &steps, &sp)) return -2;
+    if (steps > 65535) return EVAD_ERR_ARG;
+    const int sp0 = fast ? spiral_base(radius_px) : 0;
     dim3 grid(evad_blocks(N, 256));
     if (fast && variant == 1 && (radius_px == 1 || radius_px == 3)) {
 #define EVAD_RS(RR, MK) hipLaunchKernelGGL((k_build_ell_rowscan<RR, MK>), grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, \
-                                            N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters)
+                                            N, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters)
         if (radius_px == 1) { if (bitmap) EVAD_RS(1, true); else EVAD_RS(1, false); }
         else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
 #undef EVAD_RS
-    } else if (fast && !bitmap && (variant == 2 || (variant == 0 && (double)N >= 0.4 * (double)B * W * H))) {
+    } else if (fast && !bitmap && (variant == 2 || variant == 4 || (variant == 0 && (double)N >= 0.4 * (double)B * W * H))) {
         // (measured crossover against the per-event walk: 0.3-0.4 events per pixel at radius 13, below 1.4 at radius 3)
         const long long P = (long long)B * W * H;            // wave per pixel
         const long long strips = (long long)B * H * ((W + PIX_STRIP - 1) / PIX_STRIP);
@@ -1174,10 +1494,23 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         const bool int_cmp = delta_t_us > -(1 << 24) + 1 && delta_t_us < (1 << 24) - 1;
         const bool very_dense = (double)N >= 5.0 * (double)P;
 #define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, \
-                                            counters, N, n_strips, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg)
+                                            counters, N, n_strips, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg)
         // radius <= 3: all 49 steps in one 64-lane pass, one event at a time (a second pass costs a pixel three dependent
         // round trips, an event more in the loop a few hundred cycles)
-        if (steps <= 64 || (double)N < 2.0 * (double)P) { if (int_cmp) EVAD_PIX(64, true); else EVAD_PIX(64, false); }      // (... or few events per pixel)
+        // large windows at low density (or asked for: variant 4): ring bands in row-major lane order, non-empty pixels only
+        // (measured equal to the spiral-order form at 1280x720 / 0.54 events per pixel -- 4.99 against 4.96 ms -- and slower at
+        // 640x480 / 0.98: both forms are bound by instruction issue, ~600-900 per pixel, not by loads: on request only)
+        if (sp->passes.n > 0 && variant == 4) {
+            if (int_cmp) hipLaunchKernelGGL((k_build_ell_pixr<true>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, counters,
+                                            sp->band, sp->passes, N, n_strips, W, H, queue_size, delta_t_us, ell_src, ell_step, deg);
+            else         hipLaunchKernelGGL((k_build_ell_pixr<false>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, counters,
+                                            sp->band, sp->passes, N, n_strips, W, H, queue_size, delta_t_us, ell_src, ell_step, deg);
+            // non-monotone timestamps (flag on the device): the kernel above returned at once and this exact walk does the work;
+            // otherwise its workgroups return at once
+            hipLaunchKernelGGL((k_build_ell_reg<false, false>), grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
+                               steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, (unsigned*)nullptr, counters, 1);
+        }
+        else if (steps <= 64 || (double)N < 2.0 * (double)P) { if (int_cmp) EVAD_PIX(64, true); else EVAD_PIX(64, false); }      // (... or few events per pixel)
         else if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
         else                 { if (int_cmp) EVAD_PIX(32, true); else EVAD_PIX(32, false); }
 #undef EVAD_PIX
@@ -1186,13 +1519,13 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         const int threads = by_rank ? ELL_TILE : 256;
         const dim3 tgrid(evad_blocks(N, threads));
 #define EVAD_REG(MK, BR) hipLaunchKernelGGL((k_build_ell_reg<MK, BR>), tgrid, dim3(threads), 0, st, (const int2*)ev2, key_s, pix_start, \
-                               counters, N, W, H, steps, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters)
+                               counters, N, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, bitmap, counters, 0)
         if (bitmap) { if (by_rank) EVAD_REG(true, true); else EVAD_REG(true, false); }
         else        { if (by_rank) EVAD_REG(false, true); else EVAD_REG(false, false); }
 #undef EVAD_REG
     } else {                                                 // any neighbour cap / radius: the reference-style walk
         if (bitmap) return EVAD_ERR_ARG;                     // (mark with eventad_pool_edges_mark_ell afterwards)
-        hipLaunchKernelGGL(k_build_ell, grid, dim3(256), 0, st, sid, ts_s, key_s, pix_start, g_spiral_dev, counters, N, W, H,
+        hipLaunchKernelGGL(k_build_ell, grid, dim3(256), 0, st, sid, ts_s, key_s, pix_start, sp->table, counters, N, W, H,
                            steps, queue_size, delta_t_us, max_num_neighbors, ell_src, ell_step, deg);
     }
     return evad_last_error();

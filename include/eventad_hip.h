@@ -47,6 +47,11 @@ int eventad_fill_edges(const int32_t* batch, const int32_t* pos, const int32_t* 
                        void* stream);
 /* spiral.h:1-15 as a table; dxdy is HOST memory int16[(2r+1)^2][2]; returns the number of steps. */
 int eventad_spiral_offsets(int radius, int16_t* dxdy);
+/* Put the spiral tables for `radius` on the current GPU (constant-memory tables of radii 0..13 once per GPU, a device
+ * table per larger radius).  No counterpart in the reference (spiral.h computes the walk inline).  The edge-search entry
+ * points do this themselves on first use -- with a synchronous copy, which is not allowed inside a stream capture: call
+ * this once per GPU and radius before capturing.  Tables are never changed or freed afterwards. */
+int eventad_spiral_prepare(int radius);
 
 /* ---- (A') format_data for the events of a loader batch (src/dagr/utils/buffers.py:33-44) in one launch:
  * pos_out f32[N,3] = (pos_x / W, pos_y / H, t / T) with the int -> fp32 conversion and IEEE division torch applies,
@@ -109,7 +114,10 @@ int eventad_sort_events_static(const float* pos, const int64_t* batch, const flo
  * otherwise thread per event walking the spiral with the row in registers and an early exit after 16 neighbours;
  * 1 = row scan, radius 1 or 3 only (2R+1 contiguous range look-ups per event instead of (2R+1)^2 pixel
  * probes, candidates fetched 8 at a time -- sparse windows; other radii fall back to 0); 2 = wave per pixel whatever the
- * density (bitmap must be NULL, else as 3); 3 = thread per event whatever the density.  Identical rows in every case.
+ * density (bitmap must be NULL, else as 3); 3 = thread per event whatever the density; 4 = the wave-per-pixel search in its
+ * ring-band form (lanes take the pixels of a band of whole rings in row-major order, so bounds and entries are coalesced
+ * loads, and source counts are put into spiral order through an LDS table; non-empty pixels only; bitmap must be NULL; not
+ * picked by 0: it measures equal to 2 at 1280x720 and slower at 640x480).  Identical rows in every case.
  * bitmap_prezeroed != 0: the caller already cleared the bitmap. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,

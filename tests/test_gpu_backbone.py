@@ -83,8 +83,9 @@ def test_large_radius_convolution_with_a_ragged_last_group():
 
 
 # ell_variant 2 forces the wave-per-pixel edge search (the default from 0.4 events per pixel) on these sparse
-# inputs: 4 and 12 passes of 64 spiral steps, mostly empty neighbour pixels
-@pytest.mark.parametrize("ell_variant", [None, 2])
+# inputs: 4 and 12 passes of 64 spiral steps, mostly empty neighbour pixels; 4 forces its ring-band form (row-major lane
+# order inside bands of whole rings, source counts brought into spiral order through an LDS table; on request only)
+@pytest.mark.parametrize("ell_variant", [None, 2, 4])
 @pytest.mark.parametrize("W,H,n,B,span", BIG_CASES)
 def test_backbone_matches_oracle_large_sensors(W, H, n, B, span, ell_variant):
     data, cfg, outs, stages, nb, res = _setup(W, H, n, B, span, mode="ondemand", ell_variant=ell_variant)
@@ -205,7 +206,7 @@ def test_wave_per_pixel_edge_search_equals_the_walk_on_dense_input():
     dev = torch.device("cuda:0")
     nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
     outs = []
-    for variant in (3, None, 2):
+    for variant in (3, None, 2, 4):
         nb.ell_variant = variant
         outs.append(_ell_rows(nb, data, B, dev))
     assert int((outs[0][0] < 16).sum()) > 1000 and float((outs[0][0] == 16).float().mean()) > 0.5
@@ -226,12 +227,13 @@ def test_wave_per_pixel_edge_search_with_a_time_window_beyond_float_precision():
     nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
     nb.geom.delta_t_us = (1 << 24) + 5
     outs = []
-    for variant in (3, 2):
+    for variant in (3, 2, 4):
         nb.ell_variant = variant
         outs.append(_ell_rows(nb, data, 2, dev))
     assert float((outs[0][0] == 16).float().mean()) > 0.5
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
 
 
 def test_both_edge_search_kernels_give_the_same_rows():
@@ -244,7 +246,7 @@ def test_both_edge_search_kernels_give_the_same_rows():
     data = dagr_ref.format_data(data)
     dev = torch.device("cuda:0")
     outs = []
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4):
         nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
         nb.ell_variant = variant
         res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), 3, [m.to(dev) for m in data.image_feats])

@@ -46,8 +46,9 @@ def _clips(W, H, ns, **kw):
     return [synthetic.make_clip(i, W, H, n, with_image=False, precomputed_feats=True, **kw) for i, n in enumerate(ns)]
 
 
-# ell_variant: None = the edge search the density heuristic picks, 2 = the wave-per-pixel search forced
-VARIANTS = [None, 2]
+# ell_variant: None = the edge search the density heuristic picks, 2 = the wave-per-pixel search forced, 4 = its ring-band
+# form forced (row-major lane order, non-empty pixels only; non-monotone batches: the exact walk launched behind it)
+VARIANTS = [None, 2, 4]
 
 
 @pytest.mark.parametrize("ell_variant", VARIANTS)
