@@ -57,6 +57,9 @@ class NativeBackbone:
         # the last blend of a pooled Layer also scatters its rows into the next level's voxel table (one launch per level less)
         self.fused_blend_pool = os.environ.get("EVENTAD_FUSED_BLEND_POOL", "1") != "0"
         self._tail_arena_clean = False
+        # asynchronous (event-by-event) mode: rows reserved behind a dense pass for events appended later (append_events)
+        self.async_capacity = 0
+        self._n_dense = self._n_cur = 0
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         with torch.cuda.device(self.device):
             call("eventad_spiral_prepare", self.geom.radius_px)      # spiral tables on this GPU, before any capture
@@ -157,6 +160,9 @@ class NativeBackbone:
             H_.maps = [getattr(H_, "map%d" % (k + 2)).view(B, h, w, 64) for k, (h, w) in enumerate(msz)]
             hands.append(H_)
         ws["hand"] = hands
+        ws["capacity"] = N
+        if self.async_capacity > 0:                          # per-pixel lists of the events appended after a dense pass
+            ws["pix_new_head"], ws["new_next"] = i32(P), i32(self.async_capacity)
         ws["scan_tmp_tail"] = i32(1 << 10)
         # zero-initialised scratch of the pooled stage (slot tables + neighbour bitmaps of pools 2..4, error flags): ONE
         # fill at the start of tail() instead of two memsets per level.  (Separate from the front arena: the two
@@ -243,7 +249,9 @@ class NativeBackbone:
         g, st = self.geom, _stream()
         self._seq = {}
         N, B = int(pos.shape[0]), int(num_graphs)
-        ws = self._alloc(N, B)
+        if self.async_capacity > 0 and self.ws is not None and "pix_new_head" not in self.ws:
+            self._ws_key = None                              # allocated before the asynchronous mode was switched on
+        ws = self._alloc(N + self.async_capacity, B)
         self._B = B
         hand = ws["hand"][0]
         pos = pos.contiguous().float()
@@ -334,7 +342,54 @@ class NativeBackbone:
             self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.npix), L.n_max,
                  _rp(hand.n_dev), L.nx, L.ny, _rp(hand.rowptr), ptr(ws["scan_tmp"]), _rp(hand.csr_src), _rp(hand.csr_dxy),
                  _rp(hand.e_dev), st)
+        self._n_dense = self._n_cur = N
+        if self.async_capacity > 0:
+            self._c("eventad_incr_reset", ptr(ws["pix_new_head"]), B * g.H * g.W, st)
         return hand
+
+    def append_events(self, pos, polarity, batch):
+        """Asynchronous update (reference src/dagr/asynchronous/: make_model_asynchronous __init__.py:41-110, conv.py:96-190,
+        max_pool.py:245-252, over the incremental graph builder ev_graph.py:45-103): k new events, newer than every event of
+        their clip so far, are appended to the graph of the last dense pass -- their ELL rows, their layer-1 rows and the
+        pool1 voxels they touch -- at O(k) cost; the pooled stage (<= 2240 nodes per clip) is then run on the updated level-0
+        graph.  Same result dict as forward().  pos f32[k,3] normalised, polarity f32[k], batch i64[k]."""
+        ws, g, st = self.ws, self.geom, _stream()
+        if ws is None or "pix_new_head" not in ws or self._n_dense == 0:
+            raise RuntimeError("append_events needs a dense pass made with async_capacity > 0")
+        k, n_cur, K = int(pos.shape[0]), self._n_cur, g.max_neighbors
+        if n_cur + k > ws["capacity"] or n_cur + k - self._n_dense > ws["new_next"].numel():
+            raise RuntimeError("append_events: %d appended events exceed the reserved capacity (%d); run a dense pass"
+                               % (n_cur + k - self._n_dense, ws["new_next"].numel()))
+        self._seq = {}
+        hand, L, w, B = ws["hand"][0], ws["levels"][0], self.w, self._B
+        if k > 0:
+            pos = pos.contiguous().float()
+            polarity = polarity.reshape(-1).contiguous().float()
+            batch = batch.contiguous().long()
+            m0, m1 = self._front_maps
+            self._c("eventad_incr_insert", ptr(pos), ptr(polarity), ptr(batch), k, n_cur, self._n_dense, ws["capacity"], B, g.W, g.H,
+                    g.T, ptr(m0), m0.shape[1], m0.shape[2], g.voxel[0][0], g.voxel[0][1], g.grid[0][0], g.grid[0][1], ptr(ws["key_s"]),
+                    ptr(ws["ts_s"]), ptr(ws["ev2"]), ptr(ws["sid"]), ptr(ws["bev"]), ptr(ws["posn_s"]), ptr(ws["x0s"]),
+                    ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), ptr(ws["pix_new_head"]), ptr(ws["new_next"]), ptr(ws["counters"]), st)
+            self._c("eventad_incr_edges", ptr(ws["ev2"]), ptr(ws["key_s"]), ptr(ws["pix_start"]), ptr(ws["pix_new_head"]),
+                    ptr(ws["new_next"]), ptr(ws["counters"]), n_cur, k, self._n_dense, g.W, g.H, g.radius_px, g.delta_t_us, K, g.Q,
+                    ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), st)
+            self._c("eventad_l1_conv1_rows", ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]), ptr(w["lut1"]),
+                    ptr(w["shift1"]), ptr(ws["y1"]), ptr(ws["l1_work"][:256]), n_cur, n_cur + k, g.steps, K, st)
+            self._c("eventad_l1_conv2_rows", ptr(ws["y1"]), ptr(ws["x0s"]), ptr(ws["ell_src"]), ptr(ws["ell_step"]), ptr(ws["deg"]),
+                    ptr(w["lut2"]), ptr(w["wskip"]), ptr(w["shift2"]), ptr(ws["y2"]), ptr(ws["l1_work"][256:]), n_cur, n_cur + k,
+                    g.steps, K, st)
+            self._c("eventad_incr_pool0", ptr(ws["y2"]), ptr(m1), m1.shape[1], m1.shape[2], ptr(ws["posn_s"]), ptr(ws["key_s"]),
+                    ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), ptr(ws["ell_src"]), ptr(ws["deg"]), n_cur, k, g.W, g.H, ptr(L.feat),
+                    ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(L.bitmap), ptr(ws["counters"]), st)
+            self._n_cur = self._N = n_cur + k
+        # level-0 nodes, features and pooled edges from the updated slot table (the scans read counts and bitmap directly)
+        self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
+                ptr(L.bitmap), L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ), _rp(hand.x), L.ldx,
+                _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.n_dev),
+                _rp(hand.rowptr), _rp(hand.csr_src), _rp(hand.csr_dxy), _rp(hand.e_dev), None, st)
+        self._tail_arena_clean = False
+        return self.tail(hand)
 
     def tail(self, hand):
         """Pooled stage: Layers 2..5 and pools 2..4 on the level-0 graph found in `hand` (set A or B)."""
@@ -423,4 +478,6 @@ class NativeBackbone:
             raise RuntimeError("eventad_amd: pooled edge outside the 5x5x3 voxel window (unsupported geometry)")
         if f & 8:
             raise RuntimeError("eventad_amd: normalised event time outside [0,1]")
+        if f & 16:
+            raise RuntimeError("eventad_amd: asynchronous update: more than 16 appended events in one pixel (run a dense pass)")
         return f

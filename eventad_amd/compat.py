@@ -7,6 +7,7 @@ to this package --
     from dagr.utils.buffers import format_data                      (utils/train.py)
     import ev_graph_cuda                                            (src/dagr/graph/utils.py:2)
     import asy_tools                                                (src/dagr/asynchronous/*.py)
+    from dagr.asynchronous import make_model_asynchronous           (src/dagr/asynchronous/__init__.py)
 so the reference's train.py / test.py / utils run unchanged on top of the HIP path."""
 import importlib
 import sys
@@ -32,6 +33,7 @@ _ALIASES = {
     "dagr.model.networks.ema": "eventad_amd.dagr.model.networks.ema",
     "dagr.graph": "eventad_amd.dagr.graph",
     "dagr.graph.ev_graph": "eventad_amd.dagr.graph.ev_graph",
+    "dagr.asynchronous": "eventad_amd.dagr.asynchronous",          # make_model_asynchronous / make_model_synchronous
     "asy_tools": "eventad_amd.dagr.asynchronous.asy_tools",        # src/dagr/asynchronous/asy_tools (CUDA extension)
 }
 

@@ -13,6 +13,7 @@
 #define EVAD_FLAG_POS_OUT_OF_FOV 2u   // an event fell outside [0,W)x[0,H) or batch outside [0,B)
 #define EVAD_FLAG_POOL_WINDOW    4u   // a pooled edge fell outside the 5x5x3 neighbour window
 #define EVAD_FLAG_T_OUT_OF_RANGE 8u   // normalised t outside [0,1]
+#define EVAD_FLAG_INCR_OVERFLOW 16u   // incremental update: more appended events in one pixel than the edge search collects
 
 static inline int evad_last_error() {
     hipError_t e = hipGetLastError();

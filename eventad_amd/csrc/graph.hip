@@ -188,6 +188,14 @@ static int ensure_spiral(int radius, int* steps_out, const SpiralDev** entry_out
     return 0;
 }
 
+// (for the other translation units of the library) device table [steps][2] of `radius` on the current GPU
+int evad_spiral_table(int radius, int* steps, const int16_t** table) {
+    const SpiralDev* e = nullptr;
+    if (ensure_spiral(radius, steps, &e)) return -2;
+    *table = e->table;
+    return 0;
+}
+
 extern "C" int eventad_spiral_prepare(int radius) {
     if (radius < 0 || radius > 127) return EVAD_ERR_ARG;
     int steps; const SpiralDev* e = nullptr;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
                                                  const uint16_t* __restrict__ ell_step, const int* __restrict__ deg,
                                                  const float* __restrict__ lut, const float* __restrict__ shift,
                                                  const float* __restrict__ xskip, const float* __restrict__ wskip,
-                                                 float* __restrict__ out, unsigned* __restrict__ work, int N, int steps, int nlds) {
+                                                 float* __restrict__ out, unsigned* __restrict__ work, int n_first, int N, int steps, int nlds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KL = CINP == 20 ? 5 : 4;                // input channels per lane
     constexpr int LS = CINP * 16;                         // floats per LUT matrix
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
     const int xcd = blockIdx.x & 7;
     constexpr int IPG = 4 / L1_ITEM_PASSES;               // work items per group
-    const int ngroups = (N + L1_GROUP - 1) / L1_GROUP, g8 = (ngroups + 7) >> 3;
+    // destinations [n_first, N): the whole node array, or the rows appended by an incremental update
+    const int ngroups = (N - n_first + L1_GROUP - 1) / L1_GROUP, g8 = (ngroups + 7) >> 3;
     const int gbeg = xcd * g8, nitems = (min(gbeg + g8, ngroups) - gbeg) * IPG;
     unsigned* ctr = work + 32 * xcd;                      // one 128-byte line per XCD: counters sharing a line serialise like one word
     auto fetch = [&]() {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     while (item < nitems) {
         const int inext = fetch();                        // its round trip overlaps this item's work
         const int g = gbeg + item / IPG, p0 = (item % IPG) * L1_ITEM_PASSES;
-        const int n0 = g * L1_GROUP;
+        const int n0 = n_first + g * L1_GROUP;
         // rank the 64 destinations by degree (descending; ties by lane) with 17 ballots, then invert the ranking
         const int d_l = n0 + lane < N ? min(ld_off<int>(deg, 4u * (unsigned)(n0 + lane)), 16) : 0;
         int rank = 0, base = 0;
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
 
 template <int CINP, bool SKIP>
 static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_step, const int* deg, const float* lut,
-                     const float* shift, const float* xskip, const float* wskip, float* out, unsigned* work, int N, int steps,
-                     int max_nb, hipStream_t st) {
+                     const float* shift, const float* xskip, const float* wskip, float* out, unsigned* work, int n_first, int N,
+                     int steps, int max_nb, hipStream_t st) {
     constexpr int LS = CINP * 16;
     if (max_nb != 16) return EVAD_ERR_ARG;              // an ELL row is read as 4 x int4 + 4 x uint2
     if ((unsigned long long)N * 80ull > 0xffffffffull) return EVAD_ERR_ARG;     // 32-bit byte offsets into the row arrays (53 M events)
@@ -305,7 +306,7 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     int nlds = (int)((budget - fixed) / (sizeof(float) * LS)) - 2;               // spiral steps whose matrices fit beside the 2 special ones
     if (nlds > steps) nlds = steps;
     const size_t lds = fixed + sizeof(float) * (size_t)(nlds + 2) * LS;
-    const int ngroups = (int)evad_blocks(N, L1_GROUP);
+    const int ngroups = (int)evad_blocks(N - n_first, L1_GROUP);
     const int threads = whole ? L1_THREADS : 2 * L1_THREADS, waves = threads / 64;
     int wgs = (ngroups + waves - 1) / waves;            // at least one workgroup per `waves` groups ...
     const int max_wg = whole ? L1_MAX_WG : L1_MAX_WG / 2;
@@ -316,17 +317,17 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     if (nlds == steps && whole) {
         auto kern = k_l1_conv<CINP, SKIP, true, L1_THREADS, false>;
         if (attr_set[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = lds; }
-        hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
     } else {                                // large radius: inner rings in LDS, outer rings read from global memory / L2
         static size_t attr_tail = 0;
         if (3 * nlds < steps) {             // most of the table is not resident: rows ranked by their outer tail (see the kernel)
             auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, true>;
             if (attr_tail < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_tail = lds; }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
+            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
         } else {
             auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, false>;
             if (attr_set[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = lds; }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, N, steps, nlds);
+            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
         }
     }
     return evad_last_error();
@@ -338,7 +339,7 @@ extern "C" int eventad_l1_conv1(const float* x0s, const int32_t* ell_src, const 
                                 int max_num_neighbors, void* stream) {
     if (!x0s || !ell_src || !ell_step || !deg || !lut || !shift || !y1 || !work || N < 0 || steps < 1) return EVAD_ERR_ARG;
     if (N == 0) return EVAD_OK;
-    return launch_l1<20, false>(x0s, ell_src, ell_step, deg, lut, shift, nullptr, nullptr, y1, work, N, steps, max_num_neighbors,
+    return launch_l1<20, false>(x0s, ell_src, ell_step, deg, lut, shift, nullptr, nullptr, y1, work, 0, N, steps, max_num_neighbors,
                                 (hipStream_t)stream);
 }
 
@@ -350,6 +351,30 @@ extern "C" int eventad_l1_conv2(const float* y1, const float* x0s, const int32_t
     if (!y1 || !x0s || !ell_src || !ell_step || !deg || !lut || !shift || !wskip || !y2 || !work || N < 0 || steps < 1)
         return EVAD_ERR_ARG;
     if (N == 0) return EVAD_OK;
-    return launch_l1<16, true>(y1, ell_src, ell_step, deg, lut, shift, x0s, wskip, y2, work, N, steps, max_num_neighbors,
+    return launch_l1<16, true>(y1, ell_src, ell_step, deg, lut, shift, x0s, wskip, y2, work, 0, N, steps, max_num_neighbors,
+                               (hipStream_t)stream);
+}
+
+// The two convolutions on the rows [n_first, N) only: an incremental update appends nodes whose in-edges come from older
+// nodes, so the rows of the existing nodes do not change (edges point from older to newer events).  work: 256 words each,
+// cleared here.  Bit-identical to the rows a pass over all N nodes writes.
+extern "C" int eventad_l1_conv1_rows(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
+                                     const float* lut, const float* shift, float* y1, uint32_t* work, int n_first, int N,
+                                     int steps, int max_num_neighbors, void* stream) {
+    if (!x0s || !ell_src || !ell_step || !deg || !lut || !shift || !y1 || !work || n_first < 0 || N < n_first || steps < 1) return EVAD_ERR_ARG;
+    if (N == n_first) return EVAD_OK;
+    evad_zero_async(work, 256 * sizeof(uint32_t), (hipStream_t)stream);
+    return launch_l1<20, false>(x0s, ell_src, ell_step, deg, lut, shift, nullptr, nullptr, y1, work, n_first, N, steps,
+                                max_num_neighbors, (hipStream_t)stream);
+}
+
+extern "C" int eventad_l1_conv2_rows(const float* y1, const float* x0s, const int32_t* ell_src, const uint16_t* ell_step,
+                                     const int32_t* deg, const float* lut, const float* wskip, const float* shift, float* y2,
+                                     uint32_t* work, int n_first, int N, int steps, int max_num_neighbors, void* stream) {
+    if (!y1 || !x0s || !ell_src || !ell_step || !deg || !lut || !shift || !wskip || !y2 || !work || n_first < 0 || N < n_first || steps < 1)
+        return EVAD_ERR_ARG;
+    if (N == n_first) return EVAD_OK;
+    evad_zero_async(work, 256 * sizeof(uint32_t), (hipStream_t)stream);
+    return launch_l1<16, true>(y1, ell_src, ell_step, deg, lut, shift, x0s, wskip, y2, work, n_first, N, steps, max_num_neighbors,
                                (hipStream_t)stream);
 }

@@ -100,6 +100,7 @@ class Net(nn.Module):
         self.out_channels = [64, 64]
         self.out_channels_cnn = [256, 256]
         self._native = None
+        self._async_capacity, self._async_seen = 0, None
         # any load that reaches this module (its own, DAGR's or EventADModel's) makes the native weight images stale
         self.register_load_state_dict_post_hook(Net._drop_native)
 
@@ -123,8 +124,48 @@ class Net(nn.Module):
 
     @torch.no_grad()
     def forward(self, data, reset=True):
+        if self._async_capacity > 0:
+            return self.async_forward(data, reset=False)
+        return self.sync_forward(data)
+
+    @torch.no_grad()
+    def sync_forward(self, data, reset=True):
         self.front(data)
         return self.tail()
+
+    # ---- asynchronous mode (dagr.asynchronous.make_model_asynchronous)
+    def enable_asynchronous(self, capacity):
+        self._async_capacity, self._async_seen = int(capacity), None
+
+    def disable_asynchronous(self):
+        self._async_capacity, self._async_seen = 0, None
+        if self._native is not None:
+            self._native.async_capacity = 0
+
+    @torch.no_grad()
+    def async_forward(self, data, reset=False):
+        """The first call, a call with reset=True, or a batch that does not extend the events seen so far: dense pass (the
+        reference's graph initialisation, asynchronous/conv.py:28-58).  A batch with the same clips whose first rows are
+        the events already seen and whose further rows are new events (asynchronous/conv.py:108-110: more nodes than the
+        stored graph): only the new events are processed (NativeBackbone.append_events).  The caller vouches that the rows
+        already seen are unchanged and that the new events are newer than every event of their clip so far."""
+        if self._native is None:
+            self.prepare(data.pos.device)
+        nb = self._native
+        nb.async_capacity = self._async_capacity
+        N, B = int(data.pos.shape[0]), int(data.num_graphs)
+        seen = self._async_seen
+        extend = (not reset and seen is not None and seen[1] == B and seen[0] <= N and nb._n_cur == seen[0]
+                  and N - nb._n_dense <= self._async_capacity)
+        if extend:
+            n0 = seen[0]
+            res = nb.append_events(data.pos[n0:], data.x[n0:], data.batch[n0:])
+        else:
+            self.front(data)
+            res = nb.tail(nb.ws["hand"][0])
+        self._async_seen = (N, B)
+        self.last = res
+        return [GraphOut(res["out3"]), GraphOut(res["out4"])], None
 
     @torch.no_grad()
     def front(self, data):

@@ -436,6 +436,46 @@ int eventad_pool_max_bwd(const float* xa, int lda, int Ca, const float* map_nhwc
 int eventad_sample_nodes_bwd(const float* dsamp, int C, const float* npos, const int32_t* nbatch, const uint32_t* occ,
                              int nx, int ny, int B, int W, int H, int map_h, int map_w, float* dmap, void* stream);
 
+/* ---- (K) asynchronous (event-by-event) update of the event-level stage ------------------------------------------------ */
+/* Replaces src/dagr/asynchronous/ (make_model_asynchronous __init__.py:41-110, conv.py:96-190, max_pool.py:13-26,245-252)
+ * over the incremental graph builder (src/dagr/graph/ev_graph.py:45-103) for the event-level stage: k new events are
+ * appended BEHIND the arrays of the last dense pass (eventad_sort_events ... eventad_pool_seg0 on n_dense events; the
+ * arrays must hold `capacity` rows), as nodes n_cur .. n_cur+k-1 with sorted position == event id.  Edges point from older
+ * to newer events, so the rows of the existing nodes do not change.  Call order per update:
+ * eventad_incr_insert, eventad_incr_edges, eventad_l1_conv1_rows, eventad_l1_conv2_rows, eventad_incr_pool0, then
+ * eventad_pool_finalize_edges (slot_vd = NULL) and the pooled stage as after a dense pass.
+ * pix_new_head i32[B*H*W] (eventad_incr_reset after every dense pass) + new_next i32[capacity - n_dense]: per-pixel lists
+ * of the appended events. */
+int eventad_incr_reset(int32_t* pix_new_head, int64_t pixels, void* stream);
+/* The new events' node rows, exactly as a dense pass writes them: pos_new f32[k,3] normalised (format_data output),
+ * polarity_new f32[k], batch_new i64[k]; error flags as eventad_sort_events go to counters[0]. */
+int eventad_incr_insert(const float* pos_new, const float* polarity_new, const int64_t* batch_new, int k, int n_cur,
+                        int n_dense, int capacity, int B, int W, int H, int T, const float* map0_nhwc, int map_h, int map_w,
+                        float vsx, float vsy, int nx, int ny, int32_t* key_s, int32_t* ts_s, int32_t* ev2, int32_t* sid,
+                        int32_t* bev, float* posn_s, float* x0s, int32_t* node_slot, int32_t* node_vox, int32_t* pix_new_head,
+                        int32_t* new_next, uint32_t* counters, void* stream);
+/* ELL rows of nodes n_first .. n_first+k-1: the walk of ev_graph.cu:15-80 over FIFO = appended events of the pixel (newest
+ * first) ++ the dense pass's segment (newest first), queue_size entries in all -- the queue as ev_graph.cu:169-212 leaves
+ * it after inserting the new events.  More than 16 appended events in one pixel set flag 16 in counters[0]. */
+int eventad_incr_edges(const int32_t* ev2, const int32_t* key_s, const uint32_t* pix_start, const int32_t* pix_new_head,
+                       const int32_t* new_next, uint32_t* counters, int n_first, int k, int n_dense, int W, int H, int radius_px,
+                       int delta_t_us, int max_num_neighbors, int queue_size, int32_t* ell_src, uint16_t* ell_step,
+                       int32_t* deg, void* stream);
+/* eventad_l1_conv1 / eventad_l1_conv2 on rows [n_first, N) only (work: 256 words each, cleared by the call). */
+int eventad_l1_conv1_rows(const float* x0s, const int32_t* ell_src, const uint16_t* ell_step, const int32_t* deg,
+                          const float* lut, const float* shift, float* y1, uint32_t* work, int n_first, int N, int steps,
+                          int max_num_neighbors, void* stream);
+int eventad_l1_conv2_rows(const float* y1, const float* x0s, const int32_t* ell_src, const uint16_t* ell_step,
+                          const int32_t* deg, const float* lut, const float* wskip, const float* shift, float* y2,
+                          uint32_t* work, int n_first, int N, int steps, int max_num_neighbors, void* stream);
+/* Fold rows n_first .. n_first+k-1 into pool1's slot table as eventad_pool_seg0 left it (feat f32[S,80] by maximum, sums /
+ * tsum / cnt by addition, maxidx by maximum, bitmap by OR of the new in-edges' marks): integer atomics only, order
+ * independent, so the table equals the one a dense pass over all events builds. */
+int eventad_incr_pool0(const float* y2, const float* map_nhwc, int map_h, int map_w, const float* posn_s,
+                       const int32_t* key_s, const int32_t* node_slot, const int32_t* node_vox, const int32_t* ell_src,
+                       const int32_t* deg, int n_first, int k, int W, int H, float* feat, uint64_t* sums, double* tsum,
+                       uint32_t* cnt, int32_t* maxidx, uint32_t* bitmap, uint32_t* counters, void* stream);
+
 /* ---- (J) streams restricted to a CU set (no counterpart in the reference) ------------------------------------------ */
 /* A default-priority HIP stream whose kernels may only use the CUs whose bit is set in mask (u32[words], bit i = CU i).
  * TrainStep uses a pair of them with disjoint masks for the backbone graph and the head graph. */
