@@ -60,6 +60,11 @@ def test_dense_pass_equals_dense_pass_plus_asynchronous_updates(W, H, n, B, frac
     from eventad_amd.backbone import NativeBackbone
     dev = torch.device("cuda:0")
     raw = synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True)
+    if B > 1:
+        # An event at t == time_window is clustered into the NEXT clip's voxel (pooling.py:31,55-56), and that voxel's clip
+        # index is the one of whichever member the reference's scatter writes last (pooling.py:12-16): not defined by the
+        # events alone, so not comparable between two event orders.  The one-clip cases keep such an event.
+        raw.t[raw.t == 1000000] = 999999
     data = dagr_ref.format_data(raw)
     sd = weights.random_graph_state()
     maps = [m.to(dev) for m in data.image_feats]
