@@ -240,7 +240,8 @@ class NativeBackbone:
         image_feats: the five CNN feature maps ([B,C,h,w], or [B,h,w,C] if feats_are_nhwc).
         Returns a dict with out3/out4 node arrays (padded) and their device-side counts."""
         self.front(pos, polarity, batch, num_graphs, image_feats, feats_are_nhwc)
-        return self.tail(self.ws["hand"][0])
+        self._last_result = self.tail(self.ws["hand"][0])
+        return self._last_result
 
     # The forward is two stages with a flat hand-off between them, so that a training loop can overlap
     # stage `front` of batch k+2, stage `tail` of batch k+1 and the head update of batch k (TrainStep).
@@ -249,6 +250,7 @@ class NativeBackbone:
         g, st = self.geom, _stream()
         self._seq = {}
         N, B = int(pos.shape[0]), int(num_graphs)
+        self._pass_id = getattr(self, "_pass_id", 0) + 1
         if self.async_capacity > 0 and self.ws is not None and "pix_new_head" not in self.ws:
             self._ws_key = None                              # allocated before the asynchronous mode was switched on
         ws = self._alloc(N + self.async_capacity, B)

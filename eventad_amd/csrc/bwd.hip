@@ -153,16 +153,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int CINP>
 __global__ __launch_bounds__(256) void k_conv_bwd_weight(const float* __restrict__ x, const float* __restrict__ g,
                                                          const int* __restrict__ ell_src, const uint16_t* __restrict__ ell_step,
-                                                         const int* __restrict__ deg, float* __restrict__ partial, int N, int steps) {
+                                                         const int* __restrict__ deg, float* __restrict__ partial, int N, int steps,
+                                                         int band) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int bins = steps + 1, T = CINP * 16;
-    unsigned short* s_hist = (unsigned short*)smem;                          // [bins][256]: counts, then exclusive prefixes over threads
-    unsigned short* s_sorted = s_hist + (size_t)bins * BW_CHUNK;            // [4096]: slot index inside the chunk, by step
+    const int all_bins = steps + 1, T = CINP * 16;
+    // The LDS sort takes `band` spiral steps at a time (all of them up to radius 7; at radius 13 the 730 bins go in four
+    // bands): the chunk's ELL rows stay in registers, each band counts, sorts and multiplies the slots whose step lies in it.
+    unsigned short* s_hist = (unsigned short*)smem;                          // [band][256]: counts, then exclusive prefixes over threads
+    unsigned short* s_sorted = s_hist + (size_t)band * BW_CHUNK;            // [4096]: slot index inside the chunk, by step
     int* s_src = (int*)(s_sorted + BW_CHUNK * 16);                          // [4096]: source node of the slot at that position
-    unsigned* s_start = (unsigned*)(s_src + BW_CHUNK * 16);                 // [bins + 1]
+    unsigned* s_start = (unsigned*)(s_src + BW_CHUNK * 16);                 // [band + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * BW_CHUNK, i = n0 + tid;
-    for (int c = 0; c < bins; ++c) s_hist[c * BW_CHUNK + tid] = 0;
     const int d = i < N ? min(deg[i], 16) : 0;
     unsigned short cells[16];
     int srcs[16];
@@ -178,9 +180,12 @@ __global__ __launch_bounds__(256) void k_conv_bwd_weight(const float* __restrict
         const unsigned w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int k = 0; k < 16; ++k) cells[k] = (unsigned short)(k == 0 ? steps : min((int)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), steps - 1));
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (k < d) s_hist[cells[k] * BW_CHUNK + tid] += 1;      // private column: no atomics
     }
+    for (int cb = 0; cb < all_bins; cb += band) {
+    const int bins = min(band, all_bins - cb);
+    for (int c = 0; c < bins; ++c) s_hist[c * BW_CHUNK + tid] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < d && cells[k] >= cb && cells[k] < cb + bins) s_hist[(cells[k] - cb) * BW_CHUNK + tid] += 1;   // private column: no atomics
     __syncthreads();
     // per step: exclusive prefix of the counts over the 256 threads (lane = 4 consecutive threads), step totals
     for (int c = wave; c < bins; c += 4) {
@@ -210,15 +215,15 @@ __global__ __launch_bounds__(256) void k_conv_bwd_weight(const float* __restrict
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-        if (k < d) {
-            const int c = cells[k];
+        if (k < d && cells[k] >= cb && cells[k] < cb + bins) {
+            const int c = cells[k] - cb;
             const unsigned p = s_start[c] + s_hist[c * BW_CHUNK + tid];
             s_hist[c * BW_CHUNK + tid] += 1;
             s_sorted[p] = (unsigned short)(tid * 16 + k);
             s_src[p] = srcs[k];
         }
     __syncthreads();
-    float* out = partial + (size_t)blockIdx.x * bins * T;
+    float* out = partial + ((size_t)blockIdx.x * all_bins + cb) * T;
     const int j = lane >> 4, m = lane & 15;
     for (int c = wave; c < bins; c += 4) {
         const unsigned e0 = s_start[c], e1 = s_start[c + 1];
@@ -250,6 +255,8 @@ __global__ __launch_bounds__(256) void k_conv_bwd_weight(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) oc[(16 + r) * 16 + m] = D1[r];
         }
+    }
+    __syncthreads();                                         // the next band re-uses the tables
     }
 }
 
@@ -290,19 +297,22 @@ extern "C" int eventad_l1_conv_bwd_weight(const float* x, const float* g, const 
     if (!x || !g || !ell_src || !ell_step || !deg || !partial || !dlut || N < 0 || steps < 1 || (cin_pad != 20 && cin_pad != 16))
         return EVAD_ERR_ARG;
     const int T = cin_pad * 16, bins = steps + 1;
-    const size_t lds = sizeof(unsigned short) * ((size_t)bins * BW_CHUNK + BW_CHUNK * 16) + sizeof(int) * BW_CHUNK * 16 + sizeof(unsigned) * (bins + 1);
-    if (lds > 150 * 1024) return EVAD_ERR_ARG;             // search radii above 7 px: not implemented for the backward pass
+    // spiral steps sorted at a time: all of them when the tables fit 150 KiB of LDS (radius <= 7), else bands of 226
+    const size_t fixed = sizeof(unsigned short) * BW_CHUNK * 16 + sizeof(int) * BW_CHUNK * 16;
+    int band = bins;
+    while (fixed + sizeof(unsigned short) * (size_t)band * BW_CHUNK + sizeof(unsigned) * (band + 1) > 150 * 1024) band = (band + 1) / 2;
+    const size_t lds = fixed + sizeof(unsigned short) * (size_t)band * BW_CHUNK + sizeof(unsigned) * (band + 1);
     hipStream_t st = (hipStream_t)stream;
     const int parts = eventad_l1_conv_bwd_weight_parts(N);
     static size_t attr[2] = {0, 0};
     if (cin_pad == 20) {
         auto kern = k_conv_bwd_weight<20>;
         if (attr[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
-        hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps);
+        hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, band);
     } else {
         auto kern = k_conv_bwd_weight<16>;
         if (attr[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
-        hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps);
+        hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, band);
     }
     const int len = bins * T;
     hipLaunchKernelGGL(k_sum_partials, dim3(evad_blocks(len, 16)), dim3(256), 0, st, partial, parts, len, dlut);

@@ -64,6 +64,49 @@ class GraphOut:
         return torch.stack([L.csr_src[:e].long(), dst])
 
 
+class GraphOutGrad(GraphOut):
+    """GraphOut whose `x` carries autograd history (Net.forward_with_grad)."""
+
+    def __init__(self, d, x):
+        super().__init__(d)
+        self._x, self._n = x, int(x.shape[0])
+
+    @property
+    def x(self):
+        return self._x
+
+
+class _BackboneFn(torch.autograd.Function):
+    """Net.forward as ONE differentiable operation: the forward is the native pass, the backward is
+    graph_backward.BackboneBackward on the workspace that pass left behind -- what the reference gets from autograd through
+    MySplineConv / Pooling / grid_sample (spline_conv.py:39-78, pooling.py:51-97, net.py:200-228).  Inputs that receive a
+    gradient: the five CNN feature maps and the 25 weight tensors of the five Layers (the weights' VALUES are read from
+    the backbone's native images, built from the same parameters just before; they are arguments so that autograd routes
+    their gradients).  No gradient for BatchNorm parameters (eval-mode statistics are folded) or node positions."""
+
+    @staticmethod
+    def forward(ctx, net, data, nhwc, n_maps, *tensors):
+        nb = net._native
+        maps = [t.detach() for t in tensors[:n_maps]]
+        res = nb.forward(data.pos, data.x, data.batch, data.num_graphs, maps, feats_are_nhwc=nhwc)
+        n3, n4 = int(res["out3"]["n_dev"].item()), int(res["out4"]["n_dev"].item())
+        ctx.net, ctx.nhwc, ctx.n_maps, ctx.pass_id, ctx.res = net, nhwc, n_maps, nb._pass_id, res
+        return res["out3"]["x"][:n3].clone(), res["out4"]["x"][:n4].clone()
+
+    @staticmethod
+    def backward(ctx, g3, g4):
+        from ....graph_backward import BackboneBackward
+        net, nb = ctx.net, ctx.net._native
+        if nb is None or nb._pass_id != ctx.pass_id:
+            raise RuntimeError("backward through Net.forward_with_grad must run before the backbone's next pass "
+                               "(the gradients are computed on the workspace of the forward pass)")
+        sd = {"backbone." + k: v for k, v in net.state_dict().items() if not k.startswith("net.")}
+        r = BackboneBackward(nb, sd).backward(g3.contiguous().float(), g4.contiguous().float())
+        dmaps = [m if ctx.nhwc else m.permute(0, 3, 1, 2) for m in r["dmaps"]]
+        dw = [r["weights"]["backbone." + k] for k in net.grad_weight_keys()]
+        return (None, None, None, None) + tuple(dmaps) + tuple(dw)
+
+
 class Net(nn.Module):
     def __init__(self, args, height, width):
         super().__init__()
@@ -132,6 +175,30 @@ class Net(nn.Module):
     def sync_forward(self, data, reset=True):
         self.front(data)
         return self.tail()
+
+    # ---- fine-tuning the graph branch: loss.backward() reaches the Layers' weights
+    def grad_weight_keys(self):
+        """The 25 weight tensors that forward_with_grad differentiates (state-dict names)."""
+        keys = []
+        for name in LAYER_NAMES:
+            keys += ["%s.conv_block1.conv.weight" % name, "%s.conv_block1.conv.lin.weight" % name,
+                     "%s.conv_block2.conv.weight" % name, "%s.conv_block2.conv.lin.weight" % name, "%s.conv_block2.lin.mlp.weight" % name]
+        return keys
+
+    def forward_with_grad(self, data):
+        """forward() whose out3.x / out4.x carry autograd history to the weights of the five Layers and to the CNN feature
+        maps (precomputed maps that require grad; the live trunk's maps are detached: its backward is not built).  The native
+        weight images are rebuilt from the current parameters first (an optimiser step may have changed them); eval-mode
+        BatchNorm.  backward() must run before this backbone's next pass."""
+        self.prepare(data.pos.device)
+        with torch.no_grad():
+            feats, nhwc = self._maps(data)
+        named = dict(self.named_parameters())
+        params = [named[k] for k in self.grad_weight_keys()]
+        x3, x4 = _BackboneFn.apply(self, data, nhwc, len(feats), *feats, *params)
+        res = self._native._last_result
+        self.last = res
+        return [GraphOutGrad(res["out3"], x3), GraphOutGrad(res["out4"], x4)], None
 
     # ---- asynchronous mode (dagr.asynchronous.make_model_asynchronous)
     def enable_asynchronous(self, capacity):

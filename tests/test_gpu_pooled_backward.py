@@ -113,7 +113,8 @@ def test_csr_transpose_lists_every_edge_once_in_order():
 
 
 @pytest.mark.parametrize("W,H,n,B,span,seed", [(64, 64, 3000, 2, 50000, 15), (96, 64, 6000, 3, 20000, 17), (256, 256, 20000, 2, 50000, 16),
-                                               (640, 480, 20000, 2, 12000, 18)])      # search radius 7 px: table of the data gradient in memory
+                                               (640, 480, 20000, 2, 12000, 18),       # search radius 7 px: table of the data gradient in memory
+                                               (1280, 720, 12000, 2, 12000, 19)])     # radius 13: 730 LUT cells, the weight gradient's LDS sort in 4 bands
 def test_whole_graph_branch_backward_matches_autograd(W, H, n, B, span, seed):
     """out3 / out4 cotangents -> gradients of all 25 weight tensors of the five Layers and of the five CNN maps, against
     autograd through the oracle's whole Net.forward (same mask precondition as above, here also for Layer 1)."""
@@ -157,3 +158,50 @@ def test_whole_graph_branch_backward_matches_autograd(W, H, n, B, span, seed):
     res2 = bw.backward(G3.to(dev), G4.to(dev))
     assert all(torch.equal(res["weights"][k], res2["weights"][k]) for k in keys)
     assert all(torch.equal(a, b) for a, b in zip(res["dmaps"], res2["dmaps"]))
+
+
+@pytest.mark.parametrize("W,H,n,B", [(64, 64, 3000, 2), (1280, 720, 6000, 1)])
+def test_loss_backward_reaches_the_backbone_weights(W, H, n, B):
+    """Net.forward_with_grad: out3.x / out4.x carry autograd history, so a loss on them fills .grad of the 25 weight tensors
+    of the five Layers and of precomputed CNN maps -- with exactly what BackboneBackward returns (checked against autograd
+    through the oracle above) -- and an optimiser step on those weights changes the next pass."""
+    import eventad_amd.compat as compat
+    compat.install()
+    from config.eventad_config import parse_eventad_args
+    from dagr.model.networks.dagr import DAGR
+    from dagr.utils.buffers import format_data
+    from eventad_amd.graph_backward import BackboneBackward
+    dev = torch.device("cuda:0")
+    args = parse_eventad_args([])
+    args.batch_size = B
+    sd = weights.random_graph_state()
+    dagr = DAGR(args, height=H, width=W).to(dev)
+    res = dagr.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    dagr.cache_luts(radius=args.radius, height=H, width=W)
+    net = dagr.backbone
+    data = format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True, t_span_us=12000).to(dev))
+    data.image_feats = [m.clone().requires_grad_(True) for m in data.image_feats]
+    (o3, o4), _ = net.forward_with_grad(data)
+    assert o3.x.requires_grad and o4.x.requires_grad and o4.x.shape[0] == int(o4.n_dev.item())
+    g = torch.Generator().manual_seed(5)
+    G3, G4 = torch.randn(o3.x.shape, generator=g).to(dev), torch.randn(o4.x.shape, generator=g).to(dev)
+    want = BackboneBackward(net._native, {"backbone." + k: v for k, v in net.state_dict().items()}).backward(G3, G4)
+    ((o3.x * G3).sum() + (o4.x * G4).sum()).backward()
+    named = dict(net.named_parameters())
+    keys = net.grad_weight_keys()
+    assert len(keys) == 25
+    for k in keys:
+        assert named[k].grad is not None and torch.equal(named[k].grad, want["weights"]["backbone." + k]), k
+        assert float(named[k].grad.abs().max()) > 0
+    for m, dm in zip(data.image_feats, want["dmaps"]):
+        assert torch.equal(m.grad, dm.permute(0, 3, 1, 2))
+    assert all(p.grad is None for k, p in named.items() if k not in keys)           # BatchNorm / CNN parameters: no gradient
+    before = o4.x.detach().clone()
+    torch.optim.SGD([named[k] for k in keys], lr=1e-2).step()
+    (p3, p4), _ = net.forward_with_grad(data)                                       # rebuilds the native weight images
+    assert p4.x.shape == before.shape and not torch.equal(p4.x.detach(), before)
+    with pytest.raises(RuntimeError, match="next pass"):
+        (q3, q4), _ = net.forward_with_grad(data)
+        net(data)                                                                   # another pass in between
+        q4.x.sum().backward()
