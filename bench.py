@@ -169,7 +169,11 @@ def main():
     if use_graph:
         try:
             if pipelined:
-                ts.capture_dual(data)                          # backbone graph || head graph on two event-coupled streams
+                # backbone graphs || head graph on event-coupled streams; the backbone runs as far ahead of the head as the
+                # chains allow, so the timed region starts with that many finished passes in hand (as it ends with them)
+                ts.capture_dual(data, prefetch="max")
+                while ts._dual["issued"] - ts._dual["k"] < ts._dual["prefetch"]:
+                    ts.replay_dual(join=False)                 # fill: these calls only start backbone passes
                 run = lambda: ts.replay_dual(join=False)       # the timed region ends with a device-wide sync
             else:
                 ts.capture(data)
@@ -221,7 +225,7 @@ def main():
                                                                                   else "precomputed CNN feature maps", B),
                        "global_batch": world * B, "events_per_batch_per_gpu": N, "realised_edges_per_gpu": E,
                        "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
-                       "pipeline": ("none" if not pipelined else "backbone(k+1..k+%d) || head update(k): hipGraphs on event-coupled streams, %d backbone chains (own workspace set and stream each), head updates in order on one stream" % (ts._dual["n"] - 1, ts._dual["n"])),
+                       "pipeline": ("none" if not pipelined else "backbone(k+1..k+%d) || head update(k): hipGraphs on event-coupled streams, %d backbone chains (own workspace set and stream each), backbone %d batch(es) ahead, head updates in order on one stream" % (ts._dual["n"] - 1, ts._dual["n"], ts._dual["prefetch"])),
                          "cu_partition": ("head graph on %d CUs of its own, backbone graph on the others (CU-masked default-priority streams)" % ((ts.head_cus if ts.head_cus > 0 else torch.cuda.get_device_properties(0).multi_processor_count // 8)) if (pipelined and ts._dual and ts._dual.get("masked")) else "none"),
                        "input": "device-resident batch, H2D copy excluded; every step runs the full backbone + head update on it; precomputed feature maps stored channels-last (NHWC in memory)",
                        "skipped_vs_reference": "ROI pooling of the previous-frame boxes (computed by the reference, never read by its forward)",

@@ -236,9 +236,13 @@ class TrainStep:
     # backbone passes of batches k+1 and k+2 are in flight together (different streams, different workspace sets) and fill
     # each other's launch gaps.  The step object owns the static inputs, so the head always sees the boxes and labels of
     # the batch that produced its features.
-    def capture_dual(self, data, warmup=3):
+    def capture_dual(self, data, warmup=3, prefetch=1):
         """data: the first batch (formatted, on the device).  Captures the graphs on copies of it and starts the backbone
-        pass of that batch.  Every later batch must have the same shapes (events N, boxes M, clips B)."""
+        pass of that batch.  Every later batch must have the same shapes (events N, boxes M, clips B).
+        prefetch: how many batches the backbone runs ahead of the head (1 .. chains - 1; "max" = chains - 1).  With p > 1
+        the first p - 1 calls of replay_dual only start backbone passes (and return None), and the loss a call returns
+        belongs to the batch passed p calls earlier; the steady state is the same, but a caller that synchronises now and
+        then (an epoch end, a benchmark's timer) restarts with p finished passes in hand instead of one."""
         d = self._dual = {}
         in_b = d["in_b"] = [data.clone()]
         in_h = d["in_h"] = [_HeadInputs(in_b[0])]
@@ -326,7 +330,11 @@ class TrainStep:
         d["in_b_id"], d["in_h_id"] = [0] * n, [0] * n          # which loaded batch each buffer holds
         d["ev_b"] = [torch.cuda.Event() for _ in range(n)]
         d["ev_h"] = [torch.cuda.Event() for _ in range(n)]
-        d["k"], d["drained"] = 0, False
+        d["k"], d["issued"], d["drained"] = 0, 0, False        # head updates done / backbone passes started
+        p = n - 1 if prefetch == "max" else int(prefetch)
+        if not 1 <= p <= n - 1:
+            raise ValueError("capture_dual: prefetch must be between 1 and chains - 1 = %d" % (n - 1))
+        d["prefetch"] = p
         self.restore(snap)                                     # warm-up and timing replays were real steps: undone here
         torch.cuda.synchronize()
         main = torch.cuda.current_stream()
@@ -337,6 +345,7 @@ class TrainStep:
         with torch.cuda.stream(sgs[0]):                        # the first batch enters the pipeline
             self._replay_backbone(d, 0)
             d["ev_b"][0].record(sgs[0])
+        d["issued"] = 1
         self._g_loss, self._g_norm = d["out"][0]
         return d["gb"], d["gh"]
 
@@ -420,14 +429,16 @@ class TrainStep:
         n = d["n"]
         main = torch.cuda.current_stream()
         sgs, sh = self._streams(d["masked"], n)
-        c, c_next = d["k"] % n, (d["k"] + 1) % n
-        if d["drained"]:                                       # after flush(): restart the pipeline with this batch
+        c, c_next = d["k"] % n, d["issued"] % n                # chain of the head update / of the backbone pass to start
+        if d["drained"] or d["issued"] - d["k"] < d["prefetch"]:
+            # after flush(), or while the backbone is not yet `prefetch` batches ahead: only start this batch's backbone pass
             d["drained"] = False
             if join or next_batch is not None:
-                sgs[c].wait_stream(main)
-            self._issue_backbone(d, c, next_batch, sgs[c])
+                sgs[c_next].wait_stream(main)
+            self._issue_backbone(d, c_next, next_batch, sgs[c_next])
+            d["issued"] += 1
             if join:
-                main.wait_stream(sgs[c])
+                main.wait_stream(sgs[c_next])
             return None
         if join or next_batch is not None:
             sgs[c_next].wait_stream(main)                      # next_batch was produced on the caller's stream
@@ -439,25 +450,29 @@ class TrainStep:
             d["ev_h"][c].record(sh)
         self._issue_backbone(d, c_next, next_batch, sgs[c_next])
         d["k"] += 1
+        d["issued"] += 1
         if join:
             main.wait_stream(sgs[c_next]); main.wait_stream(sh)
         self._g_loss, self._g_norm = d["out"][c]
         return d["out"][c]
 
     def flush(self):
-        """Drain the pipeline: head update of the last loaded batch, no new backbone pass.  -> (loss, grad_norm).
-        The next replay_dual(batch) restarts the pipeline with `batch` (and returns None: no head update in that call)."""
+        """Drain the pipeline: head updates of every batch whose backbone pass was started, no new pass.  -> (loss, grad_norm)
+        of the last one.  The next replay_dual(batch) restarts the pipeline with `batch` (and returns None: no head update
+        in that call)."""
         d = self._dual
         n = d["n"]
         main = torch.cuda.current_stream()
         sgs, sh = self._streams(d["masked"], n)
         sh.wait_stream(main)
         c = d["k"] % n
-        with torch.cuda.stream(sh):
-            sh.wait_event(d["ev_b"][c])
-            d["gh"][c].replay()
-            d["ev_h"][c].record(sh)
-        d["k"] += 1
+        while d["k"] < d["issued"]:
+            c = d["k"] % n
+            with torch.cuda.stream(sh):
+                sh.wait_event(d["ev_b"][c])
+                d["gh"][c].replay()
+                d["ev_h"][c].record(sh)
+            d["k"] += 1
         d["drained"] = True
         main.wait_stream(sh)
         for sg in sgs:

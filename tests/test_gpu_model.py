@@ -171,19 +171,25 @@ def _run_mode(mode, ts, batches):
             ts.head_cus = 0 if "unmasked" in mode else 32
         if "chains" in mode:                             # backbone chains (default: 3 with the CU partition, else 2)
             ts.backbone_chains = int(mode.split("chains")[0][-1])
-        ts.capture_dual(batches[0], warmup=2)
+        prefetch = int(mode.split("prefetch")[1][0]) if "prefetch" in mode else 1
+        ts.capture_dual(batches[0], warmup=2, prefetch=prefetch)
         n = ts._dual["n"]
         assert ts._dual["masked"] == ("unmasked" not in mode) or "masked" not in mode
         assert n == (int(mode.split("chains")[0][-1]) if "chains" in mode else (3 if ts._dual["masked"] else 2))
         held = []
-        for b in batches[1:]:
-            loss, norm = ts.replay_dual(b, join=join)
-            held.append(loss)
+        for i, b in enumerate(batches[1:]):
+            r = ts.replay_dual(b, join=join)
+            assert (r is None) == (i < prefetch - 1)     # the first prefetch - 1 calls only start backbone passes
+            if r is None:
+                continue
+            held.append(r[0])
             if join:
-                losses.append(loss.clone())
-        held.append(ts.flush()[0])
+                losses.append(r[0].clone())
+        held.append(ts.flush()[0])                       # (runs the head updates of all batches still in the pipeline)
         torch.cuda.synchronize()
-        if join:
+        if prefetch > 1:
+            losses = [held[-1].clone()]                  # flush() reports the last of its head updates only
+        elif join:
             losses.append(held[-1].clone())
         else:                                            # a chain's two result floats survive until its next turn, n steps on
             assert len({h.data_ptr() for h in held}) == min(n, len(held))
@@ -213,7 +219,8 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
     W = H = 64; B = 3; n = 3000
     results = []
     for mode in ("sequential", "pipelined", "graph", "dual", "dual_nojoin", "dual_masked", "dual_unmasked_nojoin",
-                 "dual_masked_nojoin_3chains", "dual_masked_nojoin_4chains", "dual_2chains"):
+                 "dual_masked_nojoin_3chains", "dual_masked_nojoin_4chains", "dual_2chains", "dual_masked_nojoin_3chains_prefetch2",
+                 "dual_masked_4chains_prefetch3"):
         args, model, sd, head_sd, raw, data = _build(W, H, B, n)
         from dagr.utils.buffers import format_data
         batches = [data] + [format_data(synthetic.make_batch(W, H, n, B, first_clip=3 * k, with_image=False,
@@ -271,7 +278,8 @@ def test_pipelined_steps_with_the_live_trunk_equal_sequential_steps(train_mode):
     from eventad_amd.train_step import TrainStep
     W = H = 256; B = 2; n = 6000
     results = []
-    for mode in ("sequential", "dual_nojoin", "dual_masked_nojoin_3chains", "dual_unmasked_nojoin", "graph"):
+    for mode in ("sequential", "dual_nojoin", "dual_masked_nojoin_3chains", "dual_unmasked_nojoin", "graph",
+                 "dual_masked_nojoin_3chains_prefetch2"):
         args, model, sd, head_sd, raw, data = _build(W, H, B, n, live_cnn=True)
         batches = [data] + [format_data(synthetic.make_batch(W, H, n, B, first_clip=B * k, with_image=True).to("cuda:0"))
                             for k in range(1, 6)]
