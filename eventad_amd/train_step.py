@@ -256,7 +256,7 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._pin_workspaces()
-        d["gb"], d["gh"], d["feats"], d["out"], d["mask_step"] = [], [], [], [], []
+        d["gb"], d["gh"], d["feats"], d["out"], d["mask_step"], d["masks"] = [], [], [], [], [], []
         native = getattr(self.model.dagr_model.backbone, "_native", None)
 
         def add_chain():
@@ -278,6 +278,7 @@ class TrainStep:
                     masks = torch.empty((2 * in_h[c].num_graphs * 32, 256), device=in_h[c].bbox.device)
                     step_dev = torch.zeros(1, dtype=torch.int64, device=masks.device)   # set before each replay (_issue_backbone)
                 d["mask_step"].append(step_dev)
+                d["masks"].append(masks)                       # the graphs hold raw pointers: the buffer must outlive this call
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     feats = self.model.extract_features(in_b[c], frames=(1,))
                     if masks is not None:
@@ -289,6 +290,7 @@ class TrainStep:
                     loss, norm = self._head_update(feats, in_h[c], masks=masks)
                     self._copy_pairs([(res[0:1], loss.reshape(1)), (res[1:2], norm.reshape(1))])
                 out = (res[0], res[1])
+                d.setdefault("res", []).append(res)
                 if native is not None:
                     native.select_workspace(0)
             d["gb"].append(gb); d["gh"].append(gh); d["feats"].append(feats); d["out"].append(out)

@@ -203,11 +203,11 @@ def _assert_same_training(results):
     ref = results[0]
     steps = len(ref[1])
     assert len(set(ref[1])) == steps                          # different batches, different losses
-    for got in results[1:]:
-        assert got[2] == ref[2] == float(steps)               # optimiser step count
-        assert got[1] == ref[1][-len(got[1]):]                # every loss the mode reported, bit for bit
+    for i, got in enumerate(results[1:]):
+        assert got[2] == ref[2] == float(steps), i            # optimiser step count
+        assert got[1] == ref[1][-len(got[1]):], (i, got[1], ref[1])   # every loss the mode reported, bit for bit
         for k in ref[0]:
-            assert torch.equal(got[0][k], ref[0][k]), k       # the whole path is free of float atomics: bitwise reproducible
+            assert torch.equal(got[0][k], ref[0][k]), (i, k)  # the whole path is free of float atomics: bitwise reproducible
 
 
 def test_pipelined_and_graph_steps_equal_sequential_steps():
@@ -250,6 +250,8 @@ def test_more_than_two_chains_without_the_cu_partition_are_refused():
 @pytest.mark.skip(reason="more than two backbone chains on unpartitioned (whole-chip) streams: a run of this mode at 32 M events "
                          "faulted the GPU and the cause is not established; TrainStep.capture_dual refuses the mode")
 def test_three_and_four_unpartitioned_chains_equal_sequential_steps():
+    import eventad_amd.compat as compat
+    compat.install()
     from eventad_amd import synthetic
     from dagr.utils.buffers import format_data
     from eventad_amd.train_step import TrainStep
@@ -273,6 +275,8 @@ def test_pipelined_steps_with_the_live_trunk_equal_sequential_steps(train_mode):
     per-step join (the bench's form for live-trunk configurations) and three chains beside the CU-partitioned head.
     train_mode: dropout active, masks drawn inside the chain's backbone graph -- the generator is consumed in step order in
     every form, so the weights still agree bit for bit."""
+    import eventad_amd.compat as compat
+    compat.install()
     from eventad_amd import synthetic
     from dagr.utils.buffers import format_data
     from eventad_amd.train_step import TrainStep
