@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // steps per pass.
 // Rows are assembled in LDS and written as whole lines.  Batches whose timestamps are not monotone take an exact
 // per-event walk (the `continue` of the reference matters then).
-#define PIX_DEPTH 8
+#define PIX_DEPTH 8            // (default; k_build_ell_pix takes the depth as a template argument)
 // LDS written by one lane and read by another lane of the same wave: the LDS unit executes one wave's instructions in
 // order, so only the compiler has to keep them in order.  (A wavefront-scope fence also waits for every outstanding
 // global load and store -- the rows just written, the bounds requested ahead for the next pixel.)
@@ -1019,7 +1019,7 @@ __device__ __forceinline__ void pix_bounds(const unsigned* __restrict__ start, i
     st = ok ? (int)se.first : en;
 }
 
-template <int GS, bool INT_CMP, bool PRE>
+template <int GS, bool INT_CMP, bool PRE, int DEPTH>
 __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int N, int W, int H,
                                              int steps, int sp0, int Q, int dt_max, int x, int y, int plane_base, int i0, int md,
                                              int* my_src, unsigned short* my_stp, const int2* my_dest, int* my_cnt, int st, int en) {
@@ -1032,31 +1032,31 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
         pix_bounds(start, x, y, plane_base, W, H, c_spiral[2 * (sp0 + ii)], c_spiral[2 * (sp0 + ii) + 1], i < steps, st, en);
     }
     const int lo = max(st, en - Q);                          // the FIFO keeps only the newest Q ids
-    const int len = en - lo, lenr = min(len, PIX_DEPTH), ninv = PIX_DEPTH - lenr;
+    const int len = en - lo, lenr = min(len, DEPTH), ninv = DEPTH - lenr;
     // oldest entry of a deep pixel: if even that one is not older than the event, nothing below the registers is
-    const int eold = len > PIX_DEPTH ? ev2[min(lo, N - 1)].x : 0x7fffffff;
-    int eid[PIX_DEPTH], et[PIX_DEPTH];
+    const int eold = len > DEPTH ? ev2[min(lo, N - 1)].x : 0x7fffffff;
+    int eid[DEPTH], et[DEPTH];
     // Padding (entries past the segment's length) counts as "not older" -- subtracted again through ninv -- and as out of
     // the time window.  The asm statement keeps the padded values (two compares per entry and event below, instead of a
     // mask per entry carried into the loop) and the two load sequences apart.
 #define PIX_ENTRY(V, CX, CY) { eid[V] = (V) < lenr ? (CX) : 0x7fffffff; et[V] = (V) < lenr ? (CY) : -(1 << 30); \
                                asm volatile("" : "+v"(eid[V]), "+v"(et[V])); }
-    // The PIX_DEPTH newest entries end at en - 1: one base address, 16-byte loads of two entries each (entries are 8-byte
+    // The DEPTH newest entries end at en - 1: one base address, 16-byte loads of two entries each (entries are 8-byte
     // aligned, which is all a global load needs; an odd length reads one entry of the neighbouring segment, harmless).  A
-    // lane only asks for the pairs its segment has.  Only a wave that touches the first PIX_DEPTH events of the whole array
+    // lane only asks for the pairs its segment has.  Only a wave that touches the first DEPTH events of the whole array
     // clamps every index instead.
-    if (__all(N >= PIX_DEPTH && (en >= PIX_DEPTH || len == 0))) {
+    if (__all(N >= DEPTH && (en >= DEPTH || len == 0))) {
         struct __attribute__((aligned(8))) Piece { int4 v; };
-        const Piece* top = (const Piece*)(ev2 + (len > 0 ? en - PIX_DEPTH : 0));
+        const Piece* top = (const Piece*)(ev2 + (len > 0 ? en - DEPTH : 0));
 #pragma unroll
-        for (int c = 3; c >= 0; --c) {
+        for (int c = DEPTH / 2 - 1; c >= 0; --c) {
             int4 r = make_int4(0, 0, 0, 0);
-            if (lenr > 2 * (3 - c)) r = top[c].v;            // entries en - 8 + 2c (older) and en - 7 + 2c
-            PIX_ENTRY(PIX_DEPTH - 1 - 2 * c, r.x, r.y) PIX_ENTRY(PIX_DEPTH - 2 - 2 * c, r.z, r.w)
+            if (lenr > 2 * (DEPTH / 2 - 1 - c)) r = top[c].v;    // entries en - DEPTH + 2c (older) and en - DEPTH + 1 + 2c
+            PIX_ENTRY(DEPTH - 1 - 2 * c, r.x, r.y) PIX_ENTRY(DEPTH - 2 - 2 * c, r.z, r.w)
         }
     } else {
 #pragma unroll
-        for (int v = 0; v < PIX_DEPTH; ++v) { const int2 c = ev2[min(max(en - 1 - v, lo), N - 1)]; PIX_ENTRY(v, c.x, c.y) }
+        for (int v = 0; v < DEPTH; ++v) { const int2 c = ev2[min(max(en - 1 - v, lo), N - 1)]; PIX_ENTRY(v, c.x, c.y) }
     }
 #undef PIX_ENTRY
     unsigned long long todo = __ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB);   // bit d: event d still lacks sources
@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
         // representable (timestamps are microseconds inside one clip: no overflow)
         const int t_min = ts - dt_max;
 #pragma unroll
-        for (int v = 0; v < PIX_DEPTH; ++v) {
+        for (int v = 0; v < DEPTH; ++v) {
             cge += eid[v] >= me ? 1 : 0;
             if (INT_CMP) nin += et[v] >= t_min ? 1 : 0;
             else         nin += (float)(ts - et[v]) > fdt ? 0 : 1;
@@ -1090,9 +1090,9 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
         int nnew = cge - ninv;
         int nq = max(0, nin - nnew);
         if (!act) nq = 0;
-        if (act && eold < me && nnew + nq == PIX_DEPTH) {                // deep pixel, registers undecided: read on,
+        if (act && eold < me && nnew + nq == DEPTH) {                // deep pixel, registers undecided: read on,
             bool stop = false;                                           // four entries per round trip
-            for (int s = en - 1 - PIX_DEPTH; s >= lo && nq < MAXNB && !stop; s -= 4) {
+            for (int s = en - 1 - DEPTH; s >= lo && nq < MAXNB && !stop; s -= 4) {
                 int2 c[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) c[k] = ev2[max(s - k, lo)];
@@ -1163,8 +1163,8 @@ __device__ __forceinline__ void pix_walk_events(const int2* __restrict__ ev2, co
 // wave per workgroup, dealt pixel by pixel over all CUs, missed it on nearly every line and waited for L2).  Strips are
 // numbered so that each XCD (workgroup id mod 8) owns one contiguous eighth of them: its L2 then holds one band of rows.
 #define PIX_STRIP 16
-template <int GS1, bool INT_CMP>
-__global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
+template <int GS1, bool INT_CMP, int DEPTH>
+__global__ __launch_bounds__(256, DEPTH <= 2 ? 8 : 5) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
                                                       const unsigned* __restrict__ flags_in, int N, int n_strips, int W, int H, int steps,
                                                       int sp0, int Q, int dt_max, int* __restrict__ ell_src,
                                                       uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
@@ -1213,10 +1213,10 @@ __global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict
             PIX_LDS_ORDER();
             if (lane < PIX_CHUNK) my_src[lane * MAXNB] = d0 + lane;
             PIX_LDS_ORDER();
-            ell_pix_pass<GS1, INT_CMP, true>(ev2, start, N, W, H, first, sp0, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt, st1, en1);
+            ell_pix_pass<GS1, INT_CMP, true, DEPTH>(ev2, start, N, W, H, first, sp0, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt, st1, en1);
             for (int i0 = first; i0 < steps; i0 += 64) {
                 if (!__ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB)) break;
-                ell_pix_pass<64, INT_CMP, false>(ev2, start, N, W, H, steps, sp0, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt, 0, 0);
+                ell_pix_pass<64, INT_CMP, false, DEPTH>(ev2, start, N, W, H, steps, sp0, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt, 0, 0);
             }
             if (lane < md * 4) ((int4*)(ell_src + (size_t)d0 * MAXNB))[lane] = ((const int4*)my_src)[lane];
             if (lane < md * 2) ((uint4*)(ell_step + (size_t)d0 * MAXNB))[lane] = ((const uint4*)my_stp)[lane];
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256, 5) void k_build_ell_pix(const int2* __restrict
 // are requested, one pixel ahead, only for pixels that hold events.  One event at a time per wave (a pixel holds 1.3 on
 // average).  A lane keeps the PR_DEPTH newest entries of a pixel in registers; deeper pixels are read on from memory.
 #define PR_SPL 4
-#define PR_DEPTH 4
+#define PR_DEPTH 2
 #ifndef PR_WAVES
 #define PR_WAVES 4
 #endif
@@ -1281,11 +1281,14 @@ __device__ __forceinline__ void ell_pixr_pass(const int2* __restrict__ ev2, int 
 #pragma unroll
         for (int k = 0; k < PR_SPL; ++k) {
             const Piece* top = (const Piece*)(ev2 + (lenr[k] > 0 ? en[k] - PR_DEPTH : 0));
-            int4 r1 = make_int4(0, 0, 0, 0), r0 = make_int4(0, 0, 0, 0);
-            if (lenr[k] > 0) r1 = top[1].v;                  // entries en - 2 (older) and en - 1
-            if (lenr[k] > 2) r0 = top[0].v;                  // entries en - 4 and en - 3
+            int4 r1 = make_int4(0, 0, 0, 0);
+            if (lenr[k] > 0) r1 = top[PR_DEPTH / 2 - 1].v;   // entries en - 2 (older) and en - 1
             eid[k][0] = r1.z; et[k][0] = r1.w; eid[k][1] = r1.x; et[k][1] = r1.y;
-            eid[k][2] = r0.z; et[k][2] = r0.w; eid[k][3] = r0.x; et[k][3] = r0.y;
+            if (PR_DEPTH == 4) {
+                int4 r0 = make_int4(0, 0, 0, 0);
+                if (lenr[k] > 2) r0 = top[0].v;              // entries en - 4 and en - 3
+                eid[k][PR_DEPTH - 2] = r0.z; et[k][PR_DEPTH - 2] = r0.w; eid[k][PR_DEPTH - 1] = r0.x; et[k][PR_DEPTH - 1] = r0.y;
+            }
         }
     } else {
 #pragma unroll
@@ -1501,7 +1504,7 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         const int n_strips = (int)strips, wgs = (n_strips + 7) / 8 * 8;        // every XCD the same number of workgroups
         const bool int_cmp = delta_t_us > -(1 << 24) + 1 && delta_t_us < (1 << 24) - 1;
         const bool very_dense = (double)N >= 5.0 * (double)P;
-#define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, \
+#define EVAD_PIX(G1, IC) hipLaunchKernelGGL((k_build_ell_pix<G1, IC, 8>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, \
                                             counters, N, n_strips, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg)
         // radius <= 3: all 49 steps in one 64-lane pass, one event at a time (a second pass costs a pixel three dependent
         // round trips, an event more in the loop a few hundred cycles)
@@ -1517,6 +1520,15 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
             // otherwise its workgroups return at once
             hipLaunchKernelGGL((k_build_ell_reg<false, false>), grid, dim3(256), 0, st, (const int2*)ev2, key_s, pix_start, counters, N, W, H,
                                steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg, node_slot, node_vox, (unsigned*)nullptr, counters, 1);
+        }
+        else if (steps > 64 && (double)N < 1.0 * (double)P && int_cmp) {
+            // sparse pixels (at most one event per pixel on average: a pixel rarely holds more than two): the two newest entries
+            // of a neighbour pixel in registers instead of eight -- a quarter of the entry loads and compares per pass, 61
+            // registers and 8 waves per SIMD: 4.96 -> 3.3 ms on 4 M events at 1280x720 (the kernel is bound by instruction
+            // issue).  Four entries at 3 events per pixel (256x256, radius 3) lose: 0.49 against 0.41 ms, the reads from
+            // memory for pixels deeper than the registers cost more than the compares saved.
+            hipLaunchKernelGGL((k_build_ell_pix<64, true, 2>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start,
+                               counters, N, n_strips, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg);
         }
         else if (steps <= 64 || (double)N < 2.0 * (double)P) { if (int_cmp) EVAD_PIX(64, true); else EVAD_PIX(64, false); }      // (... or few events per pixel)
         else if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
