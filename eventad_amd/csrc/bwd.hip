@@ -124,14 +124,13 @@ extern "C" int eventad_l1_conv_bwd_data(const float* g, const uint32_t* out_star
         else               hipLaunchKernelGGL((k_conv_bwd_data<16, false>), grid, block, 0, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
         return evad_last_error();
     }
-    static size_t attr[2] = {0, 0};
     if (cin_pad == 20) {
         auto kern = k_conv_bwd_data<20, true>;
-        if (attr[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
+        if (evad_allow_lds((const void*)kern, lds)) return -2;
         hipLaunchKernelGGL(kern, grid, block, lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
     } else {
         auto kern = k_conv_bwd_data<16, true>;
-        if (attr[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
+        if (evad_allow_lds((const void*)kern, lds)) return -2;
         hipLaunchKernelGGL(kern, grid, block, lds, st, g, out_start, out_edge, ell_step, lut, dx, N, steps);
     }
     return evad_last_error();
@@ -304,14 +303,13 @@ extern "C" int eventad_l1_conv_bwd_weight(const float* x, const float* g, const 
     const size_t lds = fixed + sizeof(unsigned short) * (size_t)band * BW_CHUNK + sizeof(unsigned) * (band + 1);
     hipStream_t st = (hipStream_t)stream;
     const int parts = eventad_l1_conv_bwd_weight_parts(N);
-    static size_t attr[2] = {0, 0};
     if (cin_pad == 20) {
         auto kern = k_conv_bwd_weight<20>;
-        if (attr[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
+        if (evad_allow_lds((const void*)kern, lds)) return -2;
         hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, band);
     } else {
         auto kern = k_conv_bwd_weight<16>;
-        if (attr[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
+        if (evad_allow_lds((const void*)kern, lds)) return -2;
         hipLaunchKernelGGL(kern, dim3(parts), dim3(256), lds, st, x, g, ell_src, ell_step, deg, partial, N, steps, band);
     }
     const int len = bins * T;

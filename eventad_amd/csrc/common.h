@@ -20,6 +20,26 @@ static inline int evad_last_error() {
     return e == hipSuccess ? EVAD_OK : (int)e;
 }
 
+// More than 64 KB of dynamic LDS has to be allowed per kernel and per device before the launch (not a stream operation).
+// Remembered per (kernel, device) under a lock: entry points may be called from several host threads.
+#include <mutex>
+static inline int evad_allow_lds(const void* kernel, size_t bytes) {
+    struct Entry { const void* kernel; int dev; size_t bytes; };
+    static std::mutex mu;
+    static Entry tab[256];
+    static int n = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -2; }
+    std::lock_guard<std::mutex> lock(mu);
+    int at = -1;
+    for (int i = 0; i < n; ++i) if (tab[i].kernel == kernel && tab[i].dev == dev) { at = i; break; }
+    if (at >= 0 && tab[at].bytes >= bytes) return 0;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { (void)hipGetLastError(); return -2; }
+    if (at < 0 && n < 256) at = n++;
+    if (at >= 0) tab[at] = Entry{kernel, dev, bytes};
+    return 0;
+}
+
 static inline unsigned evad_blocks(long long n, int threads) {
     long long b = (n + threads - 1) / threads;
     return (unsigned)(b < 1 ? 1 : b);

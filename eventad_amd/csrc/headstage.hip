@@ -27,17 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float hs_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float hs_tanh(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
 
-// More than 64 KB of dynamic LDS has to be allowed per kernel and per device, once.
-static int hs_allow_lds(const void* kernel, int bytes, int which) {
-    static bool done[2][64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return -2; }
-    if (!done[which][dev]) {
-        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return -2; }
-        done[which][dev] = true;
-    }
-    return 0;
-}
+static int hs_allow_lds(const void* kernel, int bytes, int) { return evad_allow_lds(kernel, (size_t)bytes); }
 
 struct HsSlot {
     const float* hn_prev; const float* s_prev; const int* valid_prev; const float* w_att; float* alpha_prev; float* s_cur;

@@ -313,22 +313,18 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     if (wgs > max_wg) wgs = max_wg;                     // ... at most 16 waves per CU: the waves pull groups until none is left
     wgs = (wgs + 7) / 8 * 8;                            // every XCD gets the same number of workgroups
     dim3 grid((unsigned)wgs), block((unsigned)threads);
-    static size_t attr_set[2] = {0, 0};                 // raise the dynamic-LDS limit once per size (not a stream op)
     if (nlds == steps && whole) {
         auto kern = k_l1_conv<CINP, SKIP, true, L1_THREADS, false>;
-        if (attr_set[0] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[0] = lds; }
+        if (evad_allow_lds((const void*)kern, lds)) return -2;
         hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
-    } else {                                // large radius: inner rings in LDS, outer rings read from global memory / L2
-        static size_t attr_tail = 0;
-        if (3 * nlds < steps) {             // most of the table is not resident: rows ranked by their outer tail (see the kernel)
-            auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, true>;
-            if (attr_tail < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_tail = lds; }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
-        } else {
-            auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, false>;
-            if (attr_set[1] < lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[1] = lds; }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
-        }
+    } else if (3 * nlds < steps) {      // large radius, most of the table not resident: rows ranked by their outer tail (see the kernel)
+        auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, true>;
+        if (evad_allow_lds((const void*)kern, lds)) return -2;
+        hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
+    } else {                            // large radius: inner rings in LDS, outer rings read from global memory / L2
+        auto kern = k_l1_conv<CINP, SKIP, false, 2 * L1_THREADS, false>;
+        if (evad_allow_lds((const void*)kern, lds)) return -2;
+        hipLaunchKernelGGL(kern, grid, block, lds, st, xin, ell_src, ell_step, deg, lut, shift, xskip, wskip, out, work, n_first, N, steps, nlds);
     }
     return evad_last_error();
 }
