@@ -103,3 +103,72 @@ def test_grouped_copy_moves_every_segment_exactly():
         assert torch.equal(b, w)
     with pytest.raises(Exception):
         call("eventad_copy_group", 17, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p), 0)
+
+
+# ---- label side (eventad_amd/data/tracks.py): hand-derived cases
+TRACK_DTYPE = np.dtype([("t", "<u8"), ("x", "<f8"), ("y", "<f8"), ("w", "<f8"), ("h", "<f8"), ("class_id", "<u1"),
+                        ("class_confidence", "<f4"), ("track_id", "<u4")])
+
+
+def _tracks(rows):
+    a = np.zeros(len(rows), dtype=TRACK_DTYPE)
+    for i, (t, x, y, w, h, c, tid) in enumerate(rows):
+        a[i] = (t, x, y, w, h, c, 1.0, tid)
+    return a
+
+
+def test_track_filtering_and_frame_pairs():
+    from eventad_amd.data import tracks as T
+    assert T.construct_pairs(np.array([7, 3, 4, 9, 8])).tolist() == [[3, 4], [7, 8], [8, 9]]
+    assert T.construct_pairs(np.array([5])).shape == (0, 2)
+    mapping = T.compute_class_mapping(("car", "pedestrian"), ["pedestrian", "rider", "car", "bus"],
+                                      dict(pedestrian="pedestrian", rider=None, car="car", bus="car"))
+    assert mapping.tolist() == [1, -1, 0, 0]
+    ts = np.array([100, 200, 300, 400, 500], dtype=np.uint64)
+    tr = _tracks([(100, 30, 30, 60, 90, 2, 1), (200, 33, 30, 60, 90, 2, 1),          # car, frames 0 and 1
+                  (200, 600, 10, 90, 60, 1, 2),                                      # rider at frame 1: class dropped
+                  (300, 36, 30, 60, 90, 2, 1), (300, 300, 300, 9, 9, 0, 3),          # frame 2: car + a tiny pedestrian
+                  (500, 900, 30, 60, 90, 2, 1)])                                     # frame 4 (frame 3 has no box)
+    pairs, masks = T.filter_tracks({"seq": (tr, ts)}, image_width=320, image_height=215, class_remapping=mapping,
+                                   min_bbox_height=5, min_bbox_diag=10, scale=3)
+    # scale 3: the car is 20 x 30 (kept), the pedestrian 3 x 3 (too small), the rider has no class
+    assert masks["seq"].tolist() == [True, True, False, True, False, True]
+    assert pairs["seq"].tolist() == [[0, 1], [1, 2]]                                 # frames 0,1,2,4 are valid: runs of two
+    scaled = T.crop_tracks(T.rescale_tracks(tr, 3), 320, 215)
+    assert np.allclose(scaled["x"][:2], [10, 11]) and np.allclose(scaled["w"][0], 20) and np.allclose(scaled["h"][0], 30)
+    assert scaled["x"][5] == 300 and scaled["w"][5] == 19                            # x 300, x2 = 320 clipped to 319
+    # perfect tracks only: both frames of a pair hold the same ids and every box overlaps itself by IoU >= 0.1
+    pairs2, _ = T.filter_tracks({"seq": (tr, ts)}, 320, 215, mapping, 5, 10, scale=3, only_perfect_tracks=True)
+    assert pairs2["seq"].tolist() == [[0, 1], [1, 2]]
+    jump = tr.copy(); jump["x"][3] = 600                                             # the car jumps in frame 2: IoU 0 with frame 1
+    pairs3, _ = T.filter_tracks({"seq": (jump, ts)}, 320, 215, mapping, 5, 10, scale=3, only_perfect_tracks=True)
+    assert pairs3["seq"].tolist() == [[0, 1]]
+    a, b = _tracks([(1, 0, 0, 10, 10, 0, 1)]), _tracks([(2, 5, 0, 10, 10, 0, 1)])
+    assert abs(float(T.compute_iou(a, b)[0]) - 50 / 150) < 1e-9
+
+
+def test_sample_assembly_from_arrays():
+    from eventad_amd.data import tracks as T
+    mapping = np.array([1, -1, 0, 0])
+    ts = np.array([1_000_000, 1_050_000], dtype=np.uint64)
+    tr = _tracks([(1_000_000, 30, 30, 60, 90, 2, 5), (1_000_000, 300, 90, 90, 120, 0, 2),
+                  (1_050_000, 60, 30, 60, 90, 2, 5), (1_050_000, 330, 90, 90, 120, 0, 2)])
+    rng = np.random.default_rng(3)
+    n = 400
+    ev = dict(x=rng.integers(0, 320, n).astype(np.uint16), y=rng.integers(0, 240, n).astype(np.uint16),
+              t=np.sort(rng.integers(1_000_000, 1_050_000, n)).astype(np.int64), p=rng.integers(0, 2, n).astype(np.uint8))
+    clip = T.assemble_sample(tr, np.ones(4, bool), ts, (0, 1), ev, width=320, height=215, scale=3, class_remapping=mapping)
+    keep = ev["y"] < 215
+    assert clip["pos"].shape == (int(keep.sum()), 2) and clip["pos"].dtype == torch.int16
+    assert int(clip["t"][-1]) == 1_000_000 and torch.equal(clip["t"], torch.from_numpy((1_000_000 + ev["t"][keep] - ev["t"][keep][-1]).astype(np.int32)))
+    assert set(clip["x"].flatten().tolist()) <= {-1, 1}
+    # bbox = second frame, bbox0 = first frame: (x, y, w, h, class, track) at a third of the sensor size, classes remapped
+    assert torch.allclose(clip["bbox0"], torch.tensor([[10., 10, 20, 30, 0, 5], [100, 30, 30, 40, 1, 2]]))
+    assert torch.allclose(clip["bbox"], torch.tensor([[20., 10, 20, 30, 0, 5], [110, 30, 30, 40, 1, 2]]))
+    # a shorter window: events before t0 + 20 ms, boxes interpolated to that time (40 % of the way, sorted by track id)
+    clip2 = T.assemble_sample(tr, np.ones(4, bool), ts, (0, 1), ev, 320, 215, 3, mapping, num_us=20_000)
+    assert clip2["pos"].shape[0] == int((keep & (ev["t"] < 1_020_000)).sum())
+    assert torch.allclose(clip2["bbox"], torch.tensor([[104., 30, 30, 40, 1, 2], [14, 10, 20, 30, 0, 5]]))
+    from eventad_amd.data.events import collate_pinned
+    b = collate_pinned([clip, clip2])
+    assert b.num_graphs == 2 and b.bbox.shape == (4, 6) and b.bbox_batch.tolist() == [0, 0, 1, 1]
