@@ -59,6 +59,8 @@ class NativeBackbone:
         self._tail_arena_clean = False
         # asynchronous (event-by-event) mode: rows reserved behind a dense pass for events appended later (append_events)
         self.async_capacity = 0
+        self.async_graph = True                              # append_events replays its pooled stage from a recorded graph
+        self._async_tail = None
         self._n_dense = self._n_cur = 0
         self.timing = None            # set to {} to record (start, end) HIP events around every C-ABI call
         with torch.cuda.device(self.device):
@@ -385,13 +387,40 @@ class NativeBackbone:
                     ptr(ws["node_slot0"]), ptr(ws["node_vox0"]), ptr(ws["ell_src"]), ptr(ws["deg"]), n_cur, k, g.W, g.H, ptr(L.feat),
                     ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(L.bitmap), ptr(ws["counters"]), st)
             self._n_cur = self._N = n_cur + k
-        # level-0 nodes, features and pooled edges from the updated slot table (the scans read counts and bitmap directly)
-        self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
-                ptr(L.bitmap), L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ), _rp(hand.x), L.ldx,
-                _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.n_dev),
-                _rp(hand.rowptr), _rp(hand.csr_src), _rp(hand.csr_dxy), _rp(hand.e_dev), None, st)
-        self._tail_arena_clean = False
-        return self.tail(hand)
+        # level-0 nodes, features and pooled edges from the updated slot table, then the pooled stage: some 25 small launches
+        # whose arguments do not change between two dense passes -- recorded once per dense pass and replayed
+        if not self.async_graph or self.timing is not None:
+            self._async_tail = None
+            self._finalize0_updated(hand)
+            self._tail_arena_clean = False
+            return self.tail(hand)
+        if self._async_tail is None or self._async_tail[0] != self._pass_id:
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._finalize0_updated(hand)
+                self._tail_arena_clean = False
+                out = self.tail(hand)
+            self._async_tail = (self._pass_id, graph, out)
+        self._async_tail[1].replay()
+        return self._async_tail[2]
+
+    def _finalize0_updated(self, hand):
+        """Level-0 nodes and pooled edges again from pool1's slot table (the scans read counts and bitmap directly)."""
+        ws, g, st, B = self.ws, self.geom, _stream(), self._B
+        L = ws["levels"][0]
+        if L.S <= 131072:
+            self._c("eventad_pool_finalize_edges", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
+                    ptr(L.bitmap), L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ), _rp(hand.x), L.ldx,
+                    _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.n_dev),
+                    _rp(hand.rowptr), _rp(hand.csr_src), _rp(hand.csr_dxy), _rp(hand.e_dev), None, st)
+        else:
+            self._c("eventad_pool_finalize", ptr(L.feat), ptr(L.sums), ptr(L.tsum), ptr(L.cnt), ptr(L.maxidx), ptr(ws["bev"]),
+                    L.nx, L.ny, B, L.C, 2, 1, g.W, g.H, g.wh_inv[0], g.wh_inv[1], ptr(L.occ), ptr(ws["scan_tmp"]), _rp(hand.x), L.ldx,
+                    _rp(hand.npos), _rp(hand.npix), _rp(hand.nbatch), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.n_dev), st)
+            self._c("eventad_pool_edges_emit", ptr(L.bitmap), ptr(L.node_slot), ptr(L.slot2node), _rp(hand.npix), L.n_max,
+                    _rp(hand.n_dev), L.nx, L.ny, _rp(hand.rowptr), ptr(ws["scan_tmp"]), _rp(hand.csr_src), _rp(hand.csr_dxy),
+                    _rp(hand.e_dev), st)
 
     def tail(self, hand):
         """Pooled stage: Layers 2..5 and pools 2..4 on the level-0 graph found in `hand` (set A or B)."""

@@ -10,7 +10,7 @@
 //   1. eventad_incr_insert : the new events become nodes n_cur .. n_cur+k-1 BEHIND the pixel-sorted array of the last
 //                            dense pass (sorted position == event id for them); their layer-1 input rows are sampled, and
 //                            each is pushed onto a per-pixel list of appended events (the dense pass's pixel CSR stays);
-//   2. eventad_incr_edges  : thread per new event, the reference's spiral walk over FIFO = [appended events of the pixel,
+//   2. eventad_incr_edges  : wave per new event, the reference's spiral walk over FIFO = [appended events of the pixel,
 //                            newest first] ++ [the pixel's CSR segment, newest first], depth Q in total;
 //   3. eventad_l1_conv{1,2}_rows (layer1.hip): the two convolutions on the k new rows;
 //   4. eventad_incr_pool0  : the new rows are folded into pool1's voxel-slot table (max of the features, integer position
@@ -109,65 +109,98 @@ extern "C" int eventad_incr_insert(const float* pos_new, const float* polarity_n
 // The reference's walk (ev_graph.cu:15-80) for the appended events n_first .. n_first+k-1.  The FIFO of a pixel, as the
 // reference's queue holds it after inserting the new events (ev_graph.cu:169-212): the appended events of the pixel,
 // newest first, then the dense pass's segment, newest first; Q entries in all.
-__global__ void k_incr_edges(const int2* __restrict__ ev2, const int* __restrict__ key_s, const unsigned* __restrict__ start,
+// One WAVE per new event (an update is a handful of events and what counts is its latency: one thread walking 729 spiral
+// steps with two dependent loads each takes 0.27 ms): lane l takes spiral step i0 + l of a pass of 64 steps, walks its
+// pixel's FIFO once to count the sources it contributes, the wave scans the counts (lane order = spiral order), and the
+// lane walks again to put its sources -- newest first -- at its offset of the row, until 16 slots are taken.
+struct IncrFifo { int cand[INCR_NEWCAP]; int nc, n_new, st, en; bool overflow; };
+
+__device__ __forceinline__ void incr_fifo(const int* __restrict__ head, const int* __restrict__ next, const unsigned* __restrict__ start,
+                                          int p, int n_dense, IncrFifo& f) {
+    f.nc = 0; f.n_new = 0; f.overflow = false;
+    for (int e = head[p]; e >= 0; e = next[e - n_dense]) {                // appended events of this pixel, sorted newest first
+        ++f.n_new;
+        if (f.nc == INCR_NEWCAP) {                                        // keep the newest INCR_NEWCAP; the flag reports the loss
+            f.overflow = true;
+            if (e < f.cand[f.nc - 1]) continue;
+            --f.nc;
+        }
+        int q = f.nc++;
+        while (q > 0 && f.cand[q - 1] < e) { f.cand[q] = f.cand[q - 1]; --q; }
+        f.cand[q] = e;
+    }
+    f.st = (int)start[p]; f.en = (int)start[p + 1];
+}
+
+// sources of event (me, ts) in this FIFO, newest first; WRITE: into row[at ..] (slots < 16 only); -> their number (<= 16)
+template <bool WRITE>
+__device__ __forceinline__ int incr_walk(const int2* __restrict__ ev2, const IncrFifo& f, int me, int ts, int Q, int dt_max, bool monotone,
+                                         int* row, unsigned short* srow, int at, int step) {
+    const int depth = min(Q, f.n_new + f.en - f.st);
+    int seen = 0, n = 0;
+    bool stop = false;
+    for (int c = 0; c < f.nc && seen < depth && n < 16 && !stop; ++c, ++seen) {
+        const int2 o = ev2[f.cand[c]];
+        if (me > o.x) {
+            if ((float)(ts - o.y) > (float)dt_max) { if (monotone) stop = true; continue; }
+            if (WRITE && at + n < 16) { row[at + n] = f.cand[c]; srow[at + n] = (unsigned short)step; }
+            ++n;
+        }
+    }
+    seen = max(seen, min(f.n_new, depth));                                // (entries beyond the collected ones still take FIFO room)
+    for (int s = f.en - 1; s >= f.st && seen < depth && n < 16 && !stop; --s, ++seen) {
+        const int2 o = ev2[s];
+        if (me > o.x) {
+            if ((float)(ts - o.y) > (float)dt_max) { if (monotone) stop = true; continue; }
+            if (WRITE && at + n < 16) { row[at + n] = s; srow[at + n] = (unsigned short)step; }
+            ++n;
+        }
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(64) void k_incr_edges(const int2* __restrict__ ev2, const int* __restrict__ key_s, const unsigned* __restrict__ start,
                              const int* __restrict__ head, const int* __restrict__ next, const int16_t* __restrict__ spiral,
                              unsigned* __restrict__ flags, int n_first, int k, int n_dense, int W, int H, int steps, int Q, int dt_max,
                              int* __restrict__ ell_src, uint16_t* __restrict__ ell_step, int* __restrict__ deg) {
     constexpr int MAXNB = 16;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= k) return;
-    const int r = n_first + j;
+    __shared__ int s_row[MAXNB];
+    __shared__ unsigned short s_stp[MAXNB];
+    const int lane = threadIdx.x, r = n_first + (int)blockIdx.x;
+    if ((int)blockIdx.x >= k) return;
     const bool monotone = !(flags[0] & EVAD_FLAG_T_NOT_MONOTONE);
     const int key = key_s[r];
     const int2 mine = ev2[r];
     const int me = mine.x, ts = mine.y;
     const int x = key % W, y = (key / W) % H, plane_base = key - x - W * y;
-    int* row = ell_src + (size_t)r * MAXNB;
-    uint16_t* srow = ell_step + (size_t)r * MAXNB;
-    for (int e = 1; e < MAXNB; ++e) { row[e] = 0; srow[e] = 0; }
-    row[0] = r; srow[0] = 0;
-    int nn = 1;
+    if (lane < MAXNB) { s_row[lane] = lane == 0 ? r : 0; s_stp[lane] = 0; }
+    __syncthreads();
+    int nn = 1;                                              // (uniform: every lane sees the same scan totals)
     bool overflow = false;
-    for (int i = 0; i < steps && nn < MAXNB; ++i) {
-        const int xn = x + spiral[2 * i], yn = y + spiral[2 * i + 1];
-        if (xn < 0 || yn < 0 || xn >= W || yn >= H) continue;
-        const int p = plane_base + xn + W * yn;
-        int cand[INCR_NEWCAP], nc = 0, n_new = 0;
-        for (int e = head[p]; e >= 0; e = next[e - n_dense]) {            // appended events of this pixel, sorted newest first
-            ++n_new;
-            if (nc == INCR_NEWCAP) {                                      // keep the newest INCR_NEWCAP; the flag reports the loss
-                overflow = true;
-                if (e < cand[nc - 1]) continue;
-                --nc;
-            }
-            int q = nc++;
-            while (q > 0 && cand[q - 1] < e) { cand[q] = cand[q - 1]; --q; }
-            cand[q] = e;
+    for (int i0 = 0; i0 < steps && nn < MAXNB; i0 += 64) {
+        const int i = i0 + lane;
+        IncrFifo f;
+        f.nc = 0; f.n_new = 0; f.st = 0; f.en = 0; f.overflow = false;
+        if (i < steps) {
+            const int xn = x + spiral[2 * i], yn = y + spiral[2 * i + 1];
+            if (xn >= 0 && yn >= 0 && xn < W && yn < H) incr_fifo(head, next, start, plane_base + xn + W * yn, n_dense, f);
         }
-        const int st = (int)start[p], en = (int)start[p + 1];
-        const int depth = min(Q, n_new + en - st);
-        int seen = 0;
-        bool stop = false;
-        for (int c = 0; c < nc && seen < depth && nn < MAXNB && !stop; ++c, ++seen) {
-            const int2 o = ev2[cand[c]];
-            if (me > o.x) {
-                if ((float)(ts - o.y) > (float)dt_max) { if (monotone) stop = true; continue; }
-                row[nn] = cand[c]; srow[nn] = (uint16_t)i;
-                ++nn;
-            }
-        }
-        seen = max(seen, min(n_new, depth));                               // (entries beyond the collected ones still take FIFO room)
-        for (int s = en - 1; s >= st && seen < depth && nn < MAXNB && !stop; --s, ++seen) {
-            const int2 o = ev2[s];
-            if (me > o.x) {
-                if ((float)(ts - o.y) > (float)dt_max) { if (monotone) stop = true; continue; }
-                row[nn] = s; srow[nn] = (uint16_t)i;
-                ++nn;
-            }
-        }
+        overflow |= f.overflow;
+        const int nq = incr_walk<false>(ev2, f, me, ts, Q, dt_max, monotone, nullptr, nullptr, 0, i);
+        int inc = nq;                                        // inclusive sum over the lanes: lane order = spiral order
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        const int at = nn + inc - nq;
+        if (nq > 0 && at < MAXNB) incr_walk<true>(ev2, f, me, ts, Q, dt_max, monotone, s_row, s_stp, at, i);
+        nn = min(MAXNB, nn + __shfl(inc, 63, 64));
+        __syncthreads();
     }
-    deg[r] = nn;
-    if (overflow) atomicOr(flags, EVAD_FLAG_INCR_OVERFLOW);
+    if (lane < MAXNB) {
+        ell_src[(size_t)r * MAXNB + lane] = s_row[lane];
+        ell_step[(size_t)r * MAXNB + lane] = s_stp[lane];
+    }
+    if (lane == 0) deg[r] = nn;
+    if (__any(overflow) && lane == 0) atomicOr(flags, EVAD_FLAG_INCR_OVERFLOW);
 }
 
 extern "C" int eventad_incr_edges(const int32_t* ev2, const int32_t* key_s, const uint32_t* pix_start, const int32_t* pix_new_head,
@@ -181,7 +214,7 @@ extern "C" int eventad_incr_edges(const int32_t* ev2, const int32_t* key_s, cons
     int steps; const int16_t* table = nullptr;
     if (evad_spiral_table(radius_px, &steps, &table)) return -2;
     if (steps > 65535) return EVAD_ERR_ARG;
-    hipLaunchKernelGGL(k_incr_edges, dim3(evad_blocks(k, 64)), dim3(64), 0, (hipStream_t)stream, (const int2*)ev2, key_s, pix_start,
+    hipLaunchKernelGGL(k_incr_edges, dim3((unsigned)k), dim3(64), 0, (hipStream_t)stream, (const int2*)ev2, key_s, pix_start,
                        pix_new_head, new_next, table, counters, n_first, k, n_dense, W, H, steps, queue_size, delta_t_us, ell_src,
                        ell_step, deg);
     return evad_last_error();

@@ -54,8 +54,10 @@ def _outputs(res):
 @pytest.mark.parametrize("W,H,n,B,fracs", [(64, 64, 3000, 2, (0.9, 0.95)),          # two updates of 150 events per clip; 0.7 events per pixel
                                            (256, 256, 20000, 3, (0.97,)),           # sparse: the row-scan dense pass
                                            (64, 64, 6000, 1, (0.5, 0.75, 0.99)),    # one clip, updates of 1500 / 1440 / 60 events, several per pixel
-                                           (640, 480, 30000, 1, (0.98,))])          # radius 7
-def test_dense_pass_equals_dense_pass_plus_asynchronous_updates(W, H, n, B, fracs):
+                                           (640, 480, 30000, 1, (0.98,)),           # radius 7
+                                           (1280, 720, 60000, 1, (0.6, 0.99))])     # radius 13: twelve 64-step passes of the walk
+@pytest.mark.parametrize("graph", [True, False])             # pooled stage of an update replayed from a recorded graph | launched
+def test_dense_pass_equals_dense_pass_plus_asynchronous_updates(W, H, n, B, fracs, graph):
     from oracle import dagr_ref
     from eventad_amd.backbone import NativeBackbone
     dev = torch.device("cuda:0")
@@ -77,7 +79,7 @@ def test_dense_pass_equals_dense_pass_plus_asynchronous_updates(W, H, n, B, frac
 
     dense_rows, chunks = _split(data, fracs)
     nb = NativeBackbone(sd, W, H, dev)
-    nb.async_capacity = N
+    nb.async_capacity, nb.async_graph = N, graph
     d = dense_rows.to(dev)
     nb.forward(pos[d], x[d], batch[d], B, maps)
     got = None
