@@ -56,6 +56,8 @@ class NativeBackbone:
         self.fused_mark = True
         # the last blend of a pooled Layer also scatters its rows into the next level's voxel table (one launch per level less)
         self.fused_blend_pool = os.environ.get("EVENTAD_FUSED_BLEND_POOL", "1") != "0"
+        # the pooled levels' GEMMs compute only the kernel cells that the level's edges use (bit-identical outputs)
+        self.tail_live_cells = os.environ.get("EVENTAD_TAIL_LIVE_CELLS", "1") != "0"
         self._tail_arena_clean = False
         # asynchronous (event-by-event) mode: rows reserved behind a dense pass for events appended later (append_events)
         self.async_capacity = 0
@@ -126,7 +128,8 @@ class NativeBackbone:
         # the pooled stage's zero-initialised scratch (slot tables + neighbour bitmaps of pools 2..4, error flags) lies right
         # behind it, so that a front() pass clears both with the same fill; tail() alone (a hand-off set from elsewhere)
         # clears its part itself
-        tail_words = sum(g.grid[lv][0] * g.grid[lv][1] * (B + 1) * (128 + 8 + 3) + 8 for lv in range(1, 4)) + 4
+        live_words = [(g.grid[lv][0] * g.grid[lv][1] * (B + 1) + 63) // 64 + 3 & ~3 for lv in range(4)]     # live-cell masks
+        tail_words = sum(g.grid[lv][0] * g.grid[lv][1] * (B + 1) * (128 + 8 + 3) + 8 for lv in range(1, 4)) + sum(live_words) + 4
         tail_at = (work_at + 512 + 3) // 4 * 4
         self._front_zero_words = tail_at + tail_words - (4 + P + 1)
         both = torch.zeros(tail_at + tail_words, dtype=torch.int32, device=dev)
@@ -194,6 +197,7 @@ class NativeBackbone:
                 L.bitmap = ws["bitmap0"]
             else:
                 L.bitmap = tail_arena[toff: toff + 3 * S].view(S, 3); toff += (3 * S + 3) // 4 * 4
+            L.live = tail_arena[toff: toff + live_words[lv]]; toff += live_words[lv]
             L.node_slot = i32(S)
             if lv == 0:                                      # graph of level 0 = the front stage's hand-off (set A)
                 A_ = hands[0]
@@ -474,12 +478,23 @@ class NativeBackbone:
             # Layer lv+2 on this level's graph
             t = self.tail_w[lv]
             dvx, dvy = g.lut_div[lv + 1]
-            self._c("eventad_gemm_f32", _rp(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, _rp(L.n_dev),
-                 27 * 64, t["cin_pad"], None, None, None, None, 0, 0, st)
+            live = self.tail_live_cells
+            if live:                                         # Z only where a blend of this level reads it
+                self._c("eventad_tail_live_cells", _rp(L.csr_src), _rp(L.csr_dxy), _rp(L.e_dev), L.csr_src.numel(), dvx, dvy,
+                        ptr(L.live), (L.n_max + 63) // 64, st)
+                self._c("eventad_tail_gemm", _rp(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, _rp(L.n_dev),
+                        27 * 64, t["cin_pad"], ptr(L.live), st)
+            else:
+                self._c("eventad_gemm_f32", _rp(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, _rp(L.n_dev),
+                        27 * 64, t["cin_pad"], None, None, None, None, 0, 0, st)
             self._c("eventad_tail_blend", ptr(L.z1), 27 * 64, 25, None, 0, 0, _rp(L.rowptr), _rp(L.csr_src), _rp(L.csr_dxy),
                  L.n_max, _rp(L.n_dev), dvx, dvy, ptr(t["bn1"][0]), ptr(t["bn1"][1]), None, None, ptr(L.y1), 64, st)
-            self._c("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, _rp(L.n_dev),
-                 26 * 64, 64, None, None, None, None, 0, 0, st)
+            if live:
+                self._c("eventad_tail_gemm", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, _rp(L.n_dev),
+                        26 * 64, 64, ptr(L.live), st)
+            else:
+                self._c("eventad_gemm_f32", ptr(L.y1), 64, ptr(t["wc2"]), 26 * 64, ptr(L.z2), 26 * 64, L.n_max, _rp(L.n_dev),
+                        26 * 64, 64, None, None, None, None, 0, 0, st)
             if fused and lv < 3:
                 Ln = view[lv + 1]
                 nvx, nvy = g.voxel[lv + 1]

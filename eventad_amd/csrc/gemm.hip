@@ -48,8 +48,11 @@ __device__ __forceinline__ float epilogue(float v, int gm, int gn, const GemmEpi
 template <int TM, int TN, bool AT, bool BT>
 __global__ __launch_bounds__(256, TM * TN == 4 ? 4 : 1) void k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
                                                   float* __restrict__ C, int ldc, int M, const int* __restrict__ m_dev,
-                                                  int N, int K, GemmEpi epi) {
+                                                  int N, int K, GemmEpi epi, const unsigned* __restrict__ live, int live_blocks) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
+    // live (64x64 tiles only): word i = which of the first live_blocks 64-column blocks anyone reads of rows 64i .. 64i+63;
+    // a tile nobody reads is not computed (its part of C keeps whatever it held)
+    if (TM * TN == 1 && live && (int)blockIdx.x < live_blocks && !((live[blockIdx.y] >> blockIdx.x) & 1u)) return;
     constexpr int AL = BM * (GBK / 4) / 256, BL = BN * (GBK / 4) / 256;     // float4 loads per thread per slab
     __shared__ float As[2][GBK][BM + 4];
     __shared__ float Bs[2][GBK][BN + 4];
@@ -225,11 +228,12 @@ __global__ __launch_bounds__(256) void k_gemm_m32(const float* __restrict__ A, i
 
 template <int TM, int TN>
 static void launch_big(bool ta, bool tb, dim3 grid, hipStream_t st, const float* A, int lda, const float* Bm, int ldb,
-                       float* C, int ldc, int M, const int* m_dev, int N, int K, GemmEpi epi) {
-    if (!ta && !tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, false, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
-    else if (!ta && tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, false, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
-    else if (ta && !tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, true, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
-    else hipLaunchKernelGGL((k_gemm_f32<TM, TN, true, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi);
+                       float* C, int ldc, int M, const int* m_dev, int N, int K, GemmEpi epi, const unsigned* live = nullptr,
+                       int live_blocks = 0) {
+    if (!ta && !tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, false, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi, live, live_blocks);
+    else if (!ta && tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, false, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi, live, live_blocks);
+    else if (ta && !tb) hipLaunchKernelGGL((k_gemm_f32<TM, TN, true, false>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi, live, live_blocks);
+    else hipLaunchKernelGGL((k_gemm_f32<TM, TN, true, true>), grid, dim3(256), 0, st, A, lda, Bm, ldb, C, ldc, M, m_dev, N, K, epi, live, live_blocks);
 }
 
 int evad_gemm(bool ta, bool tb, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M,
@@ -248,6 +252,21 @@ int evad_gemm(bool ta, bool tb, const float* A, int lda, const float* Bm, int ld
 }
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Z = X . [W_0 | .. | W_24 | W_root (| W_skip)] of a pooled-level spline convolution, computed only where a blend reads it:
+// live[i] (eventad_tail_live_cells, tail.hip) names the kernel cells that the out-edges of nodes 64i .. 64i+63 use.  The
+// other 64x64 tiles of the first 25 column blocks are skipped -- their part of Z is never read.
+extern "C" int eventad_tail_gemm(const float* X, int ldx, const float* Wc, int ldw, float* Z, int ldz, int n_max,
+                                 const int32_t* n_dev, int N, int K, const uint32_t* live, void* stream) {
+    if (!X || !Wc || !Z || !n_dev || !live || n_max < 0 || N < 25 * 64 || N > 32 * 64 || (N & 63) || K < 0 || ldx < K || ldw < N ||
+        ldz < N || (ldx & 3) || (ldw & 3) || !al16(X) || !al16(Wc))
+        return EVAD_ERR_ARG;
+    if (n_max == 0) return EVAD_OK;
+    GemmEpi epi{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    launch_big<1, 1>(false, false, dim3(N / 64, (n_max + 63) / 64), (hipStream_t)stream, X, ldx, Wc, ldw, Z, ldz, n_max, n_dev, N, K, epi,
+                     live, 25);
+    return evad_last_error();
+}
 
 extern "C" int eventad_gemm_f32(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M,
                                 const int32_t* m_dev, int N, int K, const float* bias, const float* scale,

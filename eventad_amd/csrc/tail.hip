@@ -45,6 +45,59 @@ extern "C" int eventad_tail_blend(const float* Z, int ldz, int root_col, const f
     return evad_last_error();
 }
 
+// Which kernel cells the blends of a level read, per 64 source nodes: every edge ORs the (up to) four cells of its 4-tap
+// blend -- the same evad_basis1 arithmetic as evad_tail_blend_row, zero-weight taps included, since the blend reads them
+// too -- into live[src / 64].  live must be zero on entry.  The products of the other cells are not computed
+// (eventad_tail_gemm): at 256x256 the edges of pool1's graph use 9 to 12 of the 25 cells.
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void k_tail_live_cells(const int* __restrict__ csr_src, const int* __restrict__ csr_dxy,
+                                                         const int* __restrict__ e_dev, int e_max, float div_x, float div_y,
+                                                         unsigned* __restrict__ live, int n_words) {
+    // A few hundred edges share a word, and atomics on one address are served one after the other (some 0.2 us each at the
+    // L2): every workgroup gathers its edges' bits in an LDS copy of the words and sends each non-zero word once.
+    extern __shared__ unsigned s_live[];
+    if (IN_LDS) {
+        for (int i = threadIdx.x; i < n_words; i += 256) s_live[i] = 0u;
+        __syncthreads();
+    }
+    const int ne = min(*e_dev, e_max);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        const int s = csr_src[e], pk = csr_dxy[e];
+        const int dx = (int)(short)(pk & 0xffff), dy = pk >> 16;
+        const float ax = __fadd_rn(__fdiv_rn((float)dx, div_x), 0.5f), ay = __fadd_rn(__fdiv_rn((float)dy, div_y), 0.5f);
+        int ix0, ix1, iy0, iy1; float bx0, bx1, by0, by1;
+        evad_basis1(ax, &ix0, &ix1, &bx0, &bx1);
+        evad_basis1(ay, &iy0, &iy1, &by0, &by1);
+        const unsigned bits = 1u << (ix0 + 5 * iy0) | 1u << (ix1 + 5 * iy0) | 1u << (ix0 + 5 * iy1) | 1u << (ix1 + 5 * iy1);
+        const int t = s >> 6;
+        if (t >= n_words) continue;                          // (a source beyond the node count: not a row of Z)
+        if (IN_LDS) { if ((s_live[t] & bits) != bits) atomicOr(&s_live[t], bits); }
+        else if ((*(volatile unsigned*)(live + t) & bits) != bits) atomicOr(live + t, bits);
+    }
+    if (IN_LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_words; i += 256) {
+            const unsigned bits = s_live[i];
+            if (bits && (*(volatile unsigned*)(live + i) & bits) != bits) atomicOr(live + i, bits);
+        }
+    }
+}
+
+extern "C" int eventad_tail_live_cells(const int32_t* csr_src, const int32_t* csr_dxy, const int32_t* e_dev, int e_max, float div_x,
+                                       float div_y, uint32_t* live, int n_words, void* stream) {
+    if (!csr_src || !csr_dxy || !e_dev || !live || e_max < 0 || n_words < 0 || div_x <= 0 || div_y <= 0) return EVAD_ERR_ARG;
+    if (e_max == 0 || n_words == 0) return EVAD_OK;
+    unsigned blocks = evad_blocks(e_max, 2048);              // >= 8 edges per thread when the arrays are full
+    if (blocks > 256) blocks = 256;
+    if (n_words <= 8192)
+        hipLaunchKernelGGL(k_tail_live_cells<true>, dim3(blocks), dim3(256), (size_t)n_words * 4, (hipStream_t)stream, csr_src, csr_dxy,
+                           e_dev, e_max, div_x, div_y, live, n_words);
+    else
+        hipLaunchKernelGGL(k_tail_live_cells<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, csr_src, csr_dxy, e_dev, e_max,
+                           div_x, div_y, live, n_words);
+    return evad_last_error();
+}
+
 // NCHW -> NHWC for externally supplied ("precomputed") CNN feature maps: out[b,p,c] = in[b,c,p].
 // All (up to 8) map layout changes of a step in ONE launch, as 32x32 LDS-tiled transposes (coalesced on both sides;
 // the per-element kernel above reads with a stride of H*W floats).  desc: HOST array, 6 int64 per map:

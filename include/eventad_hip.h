@@ -207,6 +207,15 @@ int eventad_pool_edges_emit(const uint32_t* bitmap, const int32_t* node_slot_out
 int eventad_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, const int32_t* m_dev,
                      int N, int K, const float* bias, const float* scale, const float* shift, const float* residual,
                      int ldr, int relu, void* stream);
+/* Which of the 25 kernel cells the blends of a pooled level read, per 64 source nodes (spline_conv.py:27-36: an edge's LUT
+ * entry is a 4-tap blend of the cells around its offset): live u32[n_words >= ceil(n/64)], zero on entry, bit c of word i = some
+ * out-edge of nodes 64i..64i+63 has a tap in cell c.  e_dev = device-side edge count <= e_max. */
+int eventad_tail_live_cells(const int32_t* csr_src, const int32_t* csr_dxy, const int32_t* e_dev, int e_max, float div_x,
+                            float div_y, uint32_t* live, int n_words, void* stream);
+/* Z = X.[W_0|..|W_24|W_root(|W_skip)] (N = 26*64 or 27*64 columns) without the 64x64 tiles of cell blocks that `live` does
+ * not name: those parts of Z are left untouched and must not be read (eventad_tail_blend on the same edges does not). */
+int eventad_tail_gemm(const float* X, int ldx, const float* Wc, int ldw, float* Z, int ldz, int n_max, const int32_t* n_dev,
+                      int N, int K, const uint32_t* live, void* stream);
 /* out_i = ReLU(BN(sum_e sum_taps b*Z[src, cell] + Z[i, root]) [+ BN_skip(Zskip[i, skip])]), Cout = 64. */
 int eventad_tail_blend(const float* Z, int ldz, int root_col, const float* Zskip, int ldzs, int skip_col,
                        const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,

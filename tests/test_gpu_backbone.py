@@ -327,3 +327,49 @@ def test_fused_blend_and_pooling_equal_the_separate_launches(W, H, n, B, span):
     for (la, ya, da), (lb, yb, db) in zip(*levels):
         assert la[0] == lb[0] and all(torch.equal(p, q) for p, q in zip(la[1:], lb[1:]))
         assert torch.equal(ya, yb) and torch.equal(da, db)
+
+
+@pytest.mark.parametrize("W,H,n,B,span", [(256, 256, 20000, 3, 50000), (64, 64, 3000, 2, 50000), (1280, 720, 30000, 1, 50000)])
+def test_pooled_products_only_for_the_cells_in_use_give_the_same_levels(W, H, n, B, span):
+    """The pooled levels' Z = X.[W_0..W_24|root|skip] without the 64x64 tiles of kernel cells that no edge's 4-tap blend
+    reads (eventad_tail_live_cells + eventad_tail_gemm) leaves every level bit for bit as the full products do -- also when
+    the skipped parts of Z hold NaN -- and the masks name exactly the cells the edges use."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    data = dagr_ref.format_data(synthetic.make_batch(W, H, n, B, with_image=False, precomputed_feats=True, t_span_us=span))
+    sd = weights.random_graph_state()
+    dev = torch.device("cuda:0")
+    args = (data.pos.to(dev), data.x.to(dev), data.batch.to(dev), B, [m.to(dev) for m in data.image_feats])
+    levels, skipped = [], 0
+    for live in (True, False):
+        nb = NativeBackbone(sd, W, H, dev)
+        nb.tail_live_cells = live
+        nb.forward(*args)
+        for L in nb.ws["levels"]:
+            L.z1.fill_(float("nan")); L.z2.fill_(float("nan"))
+        nb.forward(*args)
+        torch.cuda.synchronize()
+        assert nb.check_flags() & ~1 == 0
+        levels.append([(_level(L), L.y[: int(L.n_dev.item())].cpu(), L.y1[: int(L.n_dev.item())].cpu()) for L in nb._tail_view])
+        if live:
+            for lv, L in enumerate(nb._tail_view):
+                nn, ne = int(L.n_dev.item()), int(L.e_dev.item())
+                src, pk = L.csr_src[:ne].long().cpu(), L.csr_dxy[:ne].cpu()
+                dx, dy = ((pk & 0xffff) ^ 0x8000) - 0x8000, pk >> 16
+                dvx, dvy = nb.geom.lut_div[lv + 1]
+                want = torch.zeros((nn + 63) // 64, dtype=torch.int64)
+                tx, ty = ((dx.float() / dvx + 0.5) * 4.0).long(), ((dy.float() / dvy + 0.5) * 4.0).long()
+                for cx in (tx % 5, (tx + 1) % 5):
+                    for cy in (ty % 5, (ty + 1) % 5):
+                        for t in range(want.numel()):
+                            m = (src >> 6) == t
+                            want[t] |= int((1 << (cx[m] + 5 * cy[m])).unique().sum())     # distinct powers of two: sum == OR
+                got = L.live[: want.numel()].cpu().long() & 0xFFFFFFFF
+                assert torch.equal(got, want), lv
+                skipped += sum(25 - bin(int(w)).count("1") for w in want)
+                z = L.z1[:nn].view(nn, 27, 64)
+                assert bool(torch.isfinite(z[:, 25:]).all())             # root and skip blocks always computed
+    assert skipped > 0
+    for (la, ya, y1a), (lb, yb, y1b) in zip(*levels):
+        assert la[0] == lb[0] and all(torch.equal(p, q) for p, q in zip(la[1:], lb[1:]))
+        assert bool(torch.isfinite(ya).all()) and torch.equal(ya, yb) and torch.equal(y1a, y1b)
