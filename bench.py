@@ -242,6 +242,15 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": name.split("#")[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                                "algorithmic_bytes": ab[name], "avg_launch_ms": round(ms, 4)}
+            lds_per_edge = {"eventad_l1_conv1#1": 1280, "eventad_l1_conv2#1": 1024}.get(name)
+            if lds_per_edge:
+                # What holds the layer-1 convolutions is the LDS, not the HBM: an edge's 4 lanes read its Cin x 16 weight
+                # matrix from the LUT in LDS once (Cin ds_read_b128 per lane), 128 B per clock and CU.
+                prop = torch.cuda.get_device_properties(0)
+                peak = 128.0 * prop.multi_processor_count * prop.clock_rate * 1e3 / 1e9
+                lds = lds_per_edge * E / (ms * 1e-3) / 1e9
+                out["roofline"]["lds"] = {"bytes_per_edge": lds_per_edge, "achieved": round(lds, 1), "peak": round(peak, 1),
+                                          "unit": "GB/s", "frac": round(lds / peak, 4)}
             out["stage_ms"] = {k.replace("eventad_", ""): round(v[1], 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]}
             out["backbone_ms"] = round(sum(v[1] for v in summ.values()), 4)
         if world == 1 and not a.no_cpu_baseline and (live or a.config != "C2"):

@@ -478,8 +478,10 @@ class NativeBackbone:
             # Layer lv+2 on this level's graph
             t = self.tail_w[lv]
             dvx, dvy = g.lut_div[lv + 1]
-            live = self.tail_live_cells
-            if live:                                         # Z only where a blend of this level reads it
+            # Z only where a blend of this level reads it; on the small levels the GEMMs are latency bound and the
+            # launch that gathers the masks costs more than the skipped tiles
+            live = self.tail_live_cells and L.n_max >= 4096
+            if live:
                 self._c("eventad_tail_live_cells", _rp(L.csr_src), _rp(L.csr_dxy), _rp(L.e_dev), L.csr_src.numel(), dvx, dvy,
                         ptr(L.live), (L.n_max + 63) // 64, st)
                 self._c("eventad_tail_gemm", _rp(L.x), L.ldx, ptr(t["wc1"]), 27 * 64, ptr(L.z1), 27 * 64, L.n_max, _rp(L.n_dev),

@@ -353,6 +353,8 @@ def test_pooled_products_only_for_the_cells_in_use_give_the_same_levels(W, H, n,
         levels.append([(_level(L), L.y[: int(L.n_dev.item())].cpu(), L.y1[: int(L.n_dev.item())].cpu()) for L in nb._tail_view])
         if live:
             for lv, L in enumerate(nb._tail_view):
+                if L.n_max < 4096:                           # small levels keep the full products
+                    continue
                 nn, ne = int(L.n_dev.item()), int(L.e_dev.item())
                 src, pk = L.csr_src[:ne].long().cpu(), L.csr_dxy[:ne].cpu()
                 dx, dy = ((pk & 0xffff) ^ 0x8000) - 0x8000, pk >> 16
