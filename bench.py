@@ -22,6 +22,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+LDS_CLOCK_GHZ = 2.4            # MI355X peak engine clock (MI355X_MICROARCH.md): LDS peak = 128 B per clock and CU
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
 # C-ABI call -> prefixes of the kernel names it launches, as they appear in the rocprofv3 traces / profiles/*_hbm_traffic.json
 # (the template arguments depend on the configuration: row scan or spiral walk, LUT fully or partly in LDS)
@@ -246,8 +247,7 @@ def main():
             if lds_per_edge:
                 # What holds the layer-1 convolutions is the LDS, not the HBM: an edge's 4 lanes read its Cin x 16 weight
                 # matrix from the LUT in LDS once (Cin ds_read_b128 per lane), 128 B per clock and CU.
-                prop = torch.cuda.get_device_properties(0)
-                peak = 128.0 * prop.multi_processor_count * prop.clock_rate * 1e3 / 1e9
+                peak = 128.0 * torch.cuda.get_device_properties(0).multi_processor_count * LDS_CLOCK_GHZ
                 lds = lds_per_edge * E / (ms * 1e-3) / 1e9
                 out["roofline"]["lds"] = {"bytes_per_edge": lds_per_edge, "achieved": round(lds, 1), "peak": round(peak, 1),
                                           "unit": "GB/s", "frac": round(lds / peak, 4)}
