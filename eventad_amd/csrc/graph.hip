@@ -833,12 +833,15 @@ __global__ __launch_bounds__(ELL_TILE) void k_build_ell_reg(const int2* __restri
 // arithmetic and divergence on (half-)empty pixels.  But the pixels x-R..x+R of one sensor row are ONE
 // contiguous range of the pixel-sorted event array, so a destination needs 2R+1 range look-ups, not (2R+1)^2:
 // every lane scans the events of its 2R+1 row ranges (all lanes converged; trip count = the longest range of the
-// wave), tests each candidate exactly as the reference does (older id, dt <= delta_t), and appends the
-// survivors as (spiral step << 12 | 4095 - offset in the row range) keys to a per-lane LDS list.  The <= 15
-// smallest keys in ascending order ARE the reference's edges in its order (spiral step, newest first within a
-// pixel).  Lanes with more than RS_CAP survivors, batches with a pixel deeper than the FIFO (the depth cap
-// then matters) or ranges longer than 4096 take the exact per-lane spiral walk instead.
-#define RS_CAP 32
+// wave) and tests each candidate exactly as the reference does (older id, dt <= delta_t).  The survivors of one pixel
+// are consecutive candidates (a pixel is a contiguous piece of the row range, ids and -- in a batch with monotone
+// timestamps -- times ascend inside it), so a lane keeps them as RUNS: per spiral step (offset of the run's first
+// survivor in the row range, length) in a per-lane LDS table, plus a 64-bit mask of the steps that have a run.  The
+// reference's row is then read off in its own order -- steps ascending = the mask's set bits from the lowest, newest
+// first inside a run -- until 15 sources are taken: no sorting.  (Selecting the 15 smallest of per-candidate keys, the
+// earlier form, was two thirds of the kernel's instructions.)  Batches whose timestamps are not monotone, with a pixel
+// deeper than the FIFO (the depth cap then matters) or than 31 events, or row ranges longer than 2047 take the exact
+// per-lane spiral walk instead.
 #define RS_UNR 8
 template <int MAXNB>
 __device__ __forceinline__ int ell_exact_walk(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int me, int ts,
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                            const int* __restrict__ node_slot, const int* __restrict__ node_vox,
                                                            unsigned* __restrict__ bitmap, unsigned* flags) {
     constexpr int MAXNB = 16, D = 2 * R + 1;
-    __shared__ unsigned s_key[256][RS_CAP + 1];
+    __shared__ unsigned short s_run[256][D * D + 1 + (D & 1 ? 0 : 1)];     // [lane][step] = first offset << 5 | length (odd word stride)
     __shared__ unsigned short s_stepof[D * D];
     __shared__ signed char s_dyi[D * D];
     const int tid = threadIdx.x;
@@ -895,9 +898,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     for (int e = 0; e < MAXNB; ++e) { nb[e] = 0; stp[e] = 0; }
     nb[0] = r;
     int nn = 1;
-    bool exact = lmax > Q || lmax * D > 4096;                // uniform: depth cap binding / offsets beyond 12 bits
+    // uniform: survivors of a pixel not contiguous / depth cap binding / run length or offsets beyond their bit fields
+    const bool exact = !monotone || lmax > Q || lmax > 31 || lmax * D > 2047;
     if (!exact) {
         int ra[D], rbv[D], n = 0;
+        unsigned long long mask = 0ull;                      // bit s: spiral step s has a run
         const int xlo = max(x - R, 0), xhi = min(x + R, W - 1);
 #pragma unroll
         for (int dyi = 0; dyi < D; ++dyi) {                  // all 2(2R+1) range bounds in flight at once
@@ -915,6 +920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d, 64));
             const int xbase = plane_base + W * (y + dyi - R) + x - R;   // key of the window's left-most pixel in this row
+            int cur_s = -1, cur_first = 0, cur_cnt = 0;      // the run being collected (a pixel's survivors are consecutive)
             for (int j0 = 0; j0 < maxlen; j0 += RS_UNR) {    // RS_UNR candidates (2 RS_UNR independent loads) per round trip
                 int2 ce[RS_UNR]; int kc[RS_UNR];
 #pragma unroll
@@ -925,42 +931,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
                 for (int u = 0; u < RS_UNR; ++u) {
                     if (me > ce[u].x && !((float)(ts - ce[u].y) > (float)dt_max)) {
-                        const int dxi = kc[u] - xbase;                       // 0..2R
-                        const unsigned key = ((unsigned)s_stepof[dyi * D + dxi] << 12 | (unsigned)(4095 - (j0 + u))) + 1u;
-                        if (n < RS_CAP) s_key[tid][n] = key;
-                        ++n;
+                        const int st = (int)s_stepof[dyi * D + kc[u] - xbase];        // (kc - xbase = 0..2R)
+                        if (st != cur_s) {
+                            if (cur_cnt) s_run[tid][cur_s] = (unsigned short)(cur_first << 5 | cur_cnt);
+                            mask |= 1ull << st;
+                            cur_s = st; cur_first = j0 + u; cur_cnt = 0;
+                        }
+                        ++cur_cnt; ++n;
                     }
                 }
             }
+            if (cur_cnt) s_run[tid][cur_s] = (unsigned short)(cur_first << 5 | cur_cnt);
         }
-        if (n > RS_CAP) exact = true;                        // this lane only
-        else {
-            int maxn = n;
+        // (s_run[tid] is written and read by this lane only: program order is all it needs)
+        asm volatile("" ::: "memory");
+        const int ntake = min(n, MAXNB - 1);
+        int left = 0, top = 0, cur = 0;                      // sources left in the current run, row position of its newest + 1
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) maxn = max(maxn, __shfl_xor(maxn, d, 64));
-            unsigned last = 0;
-#pragma unroll
-            for (int e = 1; e < MAXNB; ++e) {
-                unsigned best = 0xffffffffu;
-                if (e <= n) {
-                    for (int i0 = 0; i0 < maxn; i0 += 4) {               // 4 independent LDS reads per step
-                        unsigned kk[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) kk[u] = i0 + u < n ? s_key[tid][i0 + u] : 0xffffffffu;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) if (kk[u] > last && kk[u] < best) best = kk[u];
-                    }
-                    last = best;
-                    const unsigned q = best - 1u;
-                    const int step = (int)(q >> 12), j = 4095 - (int)(q & 4095u), dyi = s_dyi[step];
+        for (int e = 1; e < MAXNB; ++e) {
+            if (e <= ntake) {
+                if (left == 0) {
+                    cur = __ffsll((long long)mask) - 1;      // the next spiral step that has survivors
+                    mask &= mask - 1ull;
+                    const unsigned ent = s_run[tid][cur];
+                    left = (int)(ent & 31u);
+                    const int dyi = s_dyi[cur];
                     int base = ra[0];
 #pragma unroll
                     for (int t = 1; t < D; ++t) if (t == dyi) base = ra[t];
-                    nb[e] = base + j; stp[e] = step;
+                    top = base + (int)(ent >> 5) + left;
                 }
+                nb[e] = top - 1; stp[e] = cur;               // newest first inside a pixel
+                --top; --left;
             }
-            nn = 1 + min(n, MAXNB - 1);
         }
+        nn = 1 + ntake;
     }
     if (exact && active) nn = ell_exact_walk<MAXNB>(ev2, start, me, ts, x, y, plane_base, W, H, steps, sp0, Q, dt_max, monotone, nb, stp);
     if (active) {
