@@ -254,8 +254,11 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
 #pragma unroll
                 for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d2 ? nxt[u] : safe2, j, xv[u], xe[u]);
             }
+            // the destination's own input row for the skip branch: requested ahead of the edge loop, except in the one
+            // instantiation where holding it across the loop costs spills (there it is loaded when it is needed)
+            constexpr bool LATE_SKIP = SKIP && !ALL_IN_LDS && !BY_TAIL;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f); float ke = 0.f;
-            if (SKIP) l1_load_row<20>(xskip, safe, j, kv, ke);
+            if (SKIP && !LATE_SKIP) l1_load_row<20>(xskip, safe, j, kv, ke);
             float4 acc[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,7 +271,15 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
                 sv.x = quad_rotate(sv.x); sv.y = quad_rotate(sv.y); sv.z = quad_rotate(sv.z); sv.w = quad_rotate(sv.w);
                 cv.x = (unsigned)quad_rotate((int)cv.x); cv.y = (unsigned)quad_rotate((int)cv.y);
             }
-            if (SKIP) {                                   // skip branch on the layer's input row (conv.py:50)
+            // skip branch on the layer's input row (conv.py:50).  Behind a condition the compiler cannot see through (always
+            // true): as straight-line code its 20 weight reads are scheduled into the end of the edge loop's last trip and the
+            // reduction below, which costs the kernel 9 to 14 spilled registers; a block of its own keeps them out.  Not in
+            // the tail-ranked instantiation (1280x720): its passes are short, and there the same overlap is worth more than
+            // the 21 registers it spills around the loop (conv2 on 4 M events: 1.94 ms with, 2.20 ms without).
+            int skip_on = 1;
+            asm volatile("" : "+s"(skip_on));
+            if (SKIP && (BY_TAIL || skip_on)) {
+                if (LATE_SKIP) l1_load_row<20>(xskip, safe, j, kv, ke);
                 int sk = j * 16;
                 asm volatile("" : "+v"(sk));              // opaque: or the 20 loop-invariant weight reads are hoisted out of
                 l1_fma<5>(acc, kv, ke, s_skip + sk, rot); // every loop and held in 80 registers for the kernel's lifetime
