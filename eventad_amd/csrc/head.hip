@@ -432,7 +432,13 @@ __global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict_
                                                         double beta1, double beta2, float* __restrict__ state) {
     __shared__ float red[256];
     float s = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += NORM_BLOCKS * 256) s += g[i] * g[i];
+    // 16-byte loads (g is 16-byte aligned: eventad_clip_adamw checks); a thread adds its elements in ascending order
+    const int n4 = n >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += NORM_BLOCKS * 256) {
+        const float4 v = ((const float4*)g)[i];
+        s += v.x * v.x; s += v.y * v.y; s += v.z * v.z; s += v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[4 * n4 + threadIdx.x]; s += v * v; }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
@@ -473,25 +479,37 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __r
         if (!skip) state[0] = state[7];
     }
     if (skip) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float gi = g[i] * coef;
-    g[i] = gi;                                              // grads are left clipped, as clip_grad_norm_ does
-    float pi = p[i] * decay;
-    float mi = beta1 * m[i] + omb1 * gi;
-    float vi = beta2 * v[i] + omb2 * gi * gi;
-    m[i] = mi; v[i] = vi;
-    float denom = sqrtf(vi) / sqrtf(state[4]) + eps;
-    p[i] = pi - (lr / state[3]) * (mi / denom);
+    const float bc1 = state[3], bc2s = sqrtf(state[4]);
+    auto one = [&](float& pw, float& gw, float& mw, float& vw) {
+        const float gi = gw * coef;
+        gw = gi;                                            // grads are left clipped, as clip_grad_norm_ does
+        const float pi = pw * decay;
+        const float mi = beta1 * mw + omb1 * gi;
+        const float vi = beta2 * vw + omb2 * gi * gi;
+        mw = mi; vw = vi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        pw = pi - (lr / bc1) * (mi / denom);
+    };
+    // four consecutive elements per thread (16-byte loads and stores: the update is pure streaming, 7 floats of traffic per
+    // parameter, and runs on the head's CU share)
+    const int i = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i + 3 < n) {
+        float4 p4 = *(float4*)(p + i), g4 = *(float4*)(g + i), m4 = *(float4*)(m + i), v4 = *(float4*)(v + i);
+        one(p4.x, g4.x, m4.x, v4.x); one(p4.y, g4.y, m4.y, v4.y); one(p4.z, g4.z, m4.z, v4.z); one(p4.w, g4.w, m4.w, v4.w);
+        *(float4*)(g + i) = g4; *(float4*)(m + i) = m4; *(float4*)(v + i) = v4; *(float4*)(p + i) = p4;
+    } else {
+        for (int k = i; k < n; ++k) one(p[k], g[k], m[k], v[k]);
+    }
 }
 
 extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr,
                                   double beta1, double beta2, double eps, double weight_decay, double max_norm,
                                   float* partial, float* state, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !partial || !state || n <= 0) return EVAD_ERR_ARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sqnorm_partial, dim3(NORM_BLOCKS), dim3(256), 0, st, grads, n, partial, beta1, beta2, state);
-    hipLaunchKernelGGL(k_adamw, dim3(evad_blocks(n, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (float)lr,
+    hipLaunchKernelGGL(k_adamw, dim3(evad_blocks(((long long)n + 3) / 4, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (float)lr,
                        (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                        (float)(1.0 - lr * weight_decay), (float)max_norm, partial, state);
     return evad_last_error();
