@@ -68,6 +68,19 @@ def test_hot_pixel_exceeds_fifo_depth(ell_variant):
     assert int(res["ws"]["counters"][3].item()) >= 800                          # longest pixel segment, far beyond the FIFO depth
 
 
+@pytest.mark.parametrize("depth", [20, 40])
+def test_row_scan_with_long_runs_in_one_pixel(depth):
+    """The row scan keeps a pixel's survivors as one (first offset, length) run with a 5-bit length: 20 events in one pixel
+    stay on that path (runs longer than a row's 15 free slots are cut while the row is read off), 40 -- still inside the
+    FIFO -- send the batch to the exact walk.  Rows against the oracle either way."""
+    W = H = 64
+    clips = _clips(W, H, [3000, 2500])
+    clips[0]["pos"][1000:1000 + depth] = torch.tensor([30, 31], dtype=torch.int16)
+    clips[1]["pos"][200:200 + 2 * depth:2] = torch.tensor([7, 50], dtype=torch.int16)
+    flags, res, stages = _run(EventBatch.from_clips(clips), W, H, 2, 1)
+    assert depth <= int(res["ws"]["counters"][3].item()) <= depth + 4            # longest pixel segment: no deeper pixel around
+
+
 @pytest.mark.parametrize("ell_variant", VARIANTS)
 def test_non_monotone_timestamps_take_the_exact_scan_path(ell_variant):
     W = H = 64
