@@ -145,13 +145,33 @@ __global__ __launch_bounds__(256) void k_tail_blend_pool(
         atomicMax(&maxidx[slot], node + 1);
         node_slot[node] = slot;
     }
+    // Pooled-edge marks of the node's in-edges: all of them land in the three bitmap words of ONE slot, and atomics on one
+    // word are served one after the other -- so the wave ORs its lanes' bits first and sends each word once (the bits are
+    // evad_mark_edge's).
+    unsigned bm0 = 0, bm1 = 0, bm2 = 0;
+    bool far = false;
+    const int plane = nx * ny;
     for (unsigned e = rowptr[node] + c; e < rowptr[node + 1]; e += 64) {
         const int src = csr_src[e];
         bool sbad;
         const int ss = pool_slot_of(npos[3 * src], npos[3 * src + 1], npos[3 * src + 2], nbatch[src], vsx, vsy, nx, ny, S, &sbad);
-        evad_mark_edge(ss, slot, nx, ny, bitmap, flags);
+        if (ss == slot) continue;                            // self loop after clustering: dropped (pooling.py:62-64)
+        const int dx = ss % nx - slot % nx, dy = (ss / nx) % ny - (slot / nx) % ny, dp = ss / plane - slot / plane;
+        if (dx < -2 || dx > 2 || dy < -2 || dy > 2 || dp < -1 || dp > 1) { far = true; continue; }
+        const int bit = ((dp + 1) * 5 + (dy + 2)) * 5 + (dx + 2);
+        const unsigned mk = 1u << (bit & 31);
+        if (bit < 32) bm0 |= mk; else if (bit < 64) bm1 |= mk; else bm2 |= mk;
     }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { bm0 |= __shfl_xor(bm0, d, 64); bm1 |= __shfl_xor(bm1, d, 64); bm2 |= __shfl_xor(bm2, d, 64); }
+    if (c < 3) {
+        const unsigned w = c == 0 ? bm0 : (c == 1 ? bm1 : bm2);
+        unsigned* dst = bitmap + (size_t)slot * 3 + c;
+        if (w) atomicOr(dst, w);                             // (no read-back first: the wave has nothing left to wait for)
+    }
+    if (__any(far) && c == 0) atomicOr(flags, EVAD_FLAG_POOL_WINDOW);
 }
+
 
 extern "C" int eventad_tail_blend_pool(const float* Z, int ldz, int root_col, const float* Zskip, int ldzs, int skip_col,
                                        const uint32_t* rowptr, const int32_t* csr_src, const int32_t* csr_dxy, int n_max,
