@@ -18,7 +18,7 @@
 //
 // Mapping (64-lane waves, 16 destinations per pass, no workgroup barrier after the LUT is staged):
 //  * 64 consecutive destinations are ranked by degree with ballots and split into 4 passes of 16 destinations of (nearly)
-//    equal degree -- a wave pays for the longest row of a pass; a wave takes work items of 2 such passes from a per-XCD
+//    equal degree -- a wave pays for the longest row of a pass; a wave takes work items of 1 or 2 such passes from a per-XCD
 //    work counter (dynamic: items differ several times in edge count, and a wave's last item is the kernel's tail);
 //  * lane j of a destination's quad owns input channels {4j..4j+3} (+ channel 16+j when Cin = 20): a neighbour row
 //    costs one 16-byte (+ one 4-byte) load per lane, each byte of the row fetched once per quad, and only 4-5 registers;
@@ -35,7 +35,6 @@
 
 #define L1_THREADS 512          // 8 waves share one LDS copy of the LUT: 2 workgroups/CU = 16 waves/CU (a table that does not fit 80 KiB: 16 waves, one copy of 152 KiB)
 #define L1_GROUP 64             // destinations ranked together (4 passes of 16)
-#define L1_ITEM_PASSES 2        // passes per work item: a wave's last item is the kernel's tail, so items are half groups
 #define L1_MAX_WG 512
 
 // Per-lane addresses are formed as a 32-bit byte offset from a wave-uniform base pointer (arrays here are < 4 GiB), so
@@ -160,6 +159,11 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     // round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so the
     // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
     const int xcd = blockIdx.x & 7;
+    // Passes per work item.  A wave's last item is the kernel's tail, and items differ several times in edge count, so small
+    // items balance better -- but every item of a group repeats the group's ranking.  Measured: one pass per item wins where
+    // passes are uneven or long (tail-ranked 1280x720: conv1 3.04 -> 2.61 ms, conv2 1.95 -> 1.81; conv1 at 640x480: 8.6 ->
+    // 8.15 ms), two passes for the 16-channel convolution otherwise (640x480: 6.8 against 6.9 ms; 256x256: 79 against 81 us).
+    constexpr int L1_ITEM_PASSES = (BY_TAIL || !SKIP) ? 1 : 2;
     constexpr int IPG = 4 / L1_ITEM_PASSES;               // work items per group
     // destinations [n_first, N): the whole node array, or the rows appended by an incremental update
     const int ngroups = (N - n_first + L1_GROUP - 1) / L1_GROUP, g8 = (ngroups + 7) >> 3;
@@ -274,8 +278,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
             // skip branch on the layer's input row (conv.py:50).  Behind a condition the compiler cannot see through (always
             // true): as straight-line code its 20 weight reads are scheduled into the end of the edge loop's last trip and the
             // reduction below, which costs the kernel 9 to 14 spilled registers; a block of its own keeps them out.  Not in
-            // the tail-ranked instantiation (1280x720): its passes are short, and there the same overlap is worth more than
-            // the 21 registers it spills around the loop (conv2 on 4 M events: 1.94 ms with, 2.20 ms without).
+            // the tail-ranked instantiation (1280x720): its passes are short, and there the same overlap is worth 13 % of
+            // the kernel's time (conv2 on 4 M events: 1.94 ms with, 2.20 ms without); with one pass per work item it has
+            // the registers for it.
             int skip_on = 1;
             asm volatile("" : "+s"(skip_on));
             if (SKIP && (BY_TAIL || skip_on)) {
