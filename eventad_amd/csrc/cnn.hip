@@ -186,8 +186,8 @@ static long long conv_plan(long long M, int Cout, int K, long long have, bool& b
     const int bt = big ? 128 : 64;
     const long long tiles = ((Cout + bt - 1) / bt) * ((M + bt - 1) / bt);
     ksplit = 1; kchunk = 0;
-    if (have != 0 && tiles < 160 && K >= 512) {
-        int ks = (int)(512 / tiles);
+    if (have != 0 && tiles < 640 && K >= 512) {
+        int ks = (int)((768 + tiles - 1) / tiles);
         if (ks > 8) ks = 8;
         while (ks > 1 && (K / ks < 128 || (have > 0 && (long long)ks * MN > have))) --ks;
         if (ks > 1) {
