@@ -11,12 +11,19 @@
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int MODE>
-__global__ __launch_bounds__(256, 4) void k_steps(float* out, const float4* __restrict__ src, int slabs) {
+__global__ __launch_bounds__(256, 4) void k_steps(float* out, const float4* __restrict__ src, int slabs, int rnd) {
     __shared__ float As[2][16][132];
     __shared__ float Bs[2][16][132];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, c = lane & 31, kh2 = lane >> 5;
-    for (int i = tid; i < 2 * 16 * 132; i += 256) { (&As[0][0][0])[i] = 1e-3f * (i & 15); (&Bs[0][0][0])[i] = 1e-3f * (i & 7); }
+    for (int i = tid; i < 2 * 16 * 132; i += 256) {
+        if (rnd) {                                           // operands with busy mantissas: the data a real product sees
+            unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            (&As[0][0][0])[i] = ((h & 0xffffff) / 16777216.f - 0.5f) * 1e-2f;
+            h *= 3266489917u; h ^= h >> 16;
+            (&Bs[0][0][0])[i] = ((h & 0xffffff) / 16777216.f - 0.5f) * 1e-2f;
+        } else { (&As[0][0][0])[i] = 1e-3f * (i & 15); (&Bs[0][0][0])[i] = 1e-3f * (i & 7); }
+    }
     __syncthreads();
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -69,19 +76,19 @@ __global__ __launch_bounds__(256, 4) void k_steps(float* out, const float4* __re
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
     if (sum == 12345.678f) out[0] = sum;
 }
-template <int MODE> static void run(int blocks, float* out, const float4* src, int slabs) {
+template <int MODE> static void run(int blocks, float* out, const float4* src, int slabs, int rnd = 0) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_steps<MODE>, dim3(blocks), dim3(256), 0, 0, out, src, slabs);
+        hipLaunchKernelGGL(k_steps<MODE>, dim3(blocks), dim3(256), 0, 0, out, src, slabs, rnd);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
     const double flops = (double)blocks * 4 * slabs * 32.0 * (32.0 * 32 * 2 * 2);
-    printf("mode %d: %.2f ms, %.1f TFLOP/s\n", MODE, best, flops / best / 1e9);
+    printf("mode %d%s: %.2f ms, %.1f TFLOP/s\n", MODE, rnd ? " (random operands)" : "", best, flops / best / 1e9);
 }
 int main(int argc, char** argv) {
     const int per_cu = argc > 1 ? atoi(argv[1]) : 4;
@@ -92,5 +99,6 @@ int main(int argc, char** argv) {
     printf("%d CUs, %d workgroups of 4 waves per CU\n", pr.multiProcessorCount, per_cu);
     run<0>(blocks, out, src, slabs); run<1>(blocks, out, src, slabs); run<2>(blocks, out, src, slabs);
     run<3>(blocks, out, src, slabs); run<4>(blocks, out, src, slabs); run<5>(blocks, out, src, slabs); run<6>(blocks, out, src, slabs);
+    run<2>(blocks, out, src, slabs, 1); run<2>(blocks, out, src, 4 * slabs, 1);
     return 0;
 }
