@@ -946,10 +946,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         // (s_run[tid] is written and read by this lane only: program order is all it needs)
         asm volatile("" ::: "memory");
         const int ntake = min(n, MAXNB - 1);
-        int left = 0, top = 0, cur = 0;                      // sources left in the current run, row position of its newest + 1
+        int left = 0, top = 0, cur = 0, taken = 0;           // sources left in the current run, row position of its newest + 1
 #pragma unroll
         for (int e = 1; e < MAXNB; ++e) {
-            if (e <= ntake) {
+            if (e <= ntake && (left > 0 || mask != 0ull)) {  // (the runs hold n sources; never read past the last run)
+                ++taken;
                 if (left == 0) {
                     cur = __ffsll((long long)mask) - 1;      // the next spiral step that has survivors
                     mask &= mask - 1ull;
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 --top; --left;
             }
         }
-        nn = 1 + ntake;
+        nn = 1 + taken;
     }
     if (exact && active) nn = ell_exact_walk<MAXNB>(ev2, start, me, ts, x, y, plane_base, W, H, steps, sp0, Q, dt_max, monotone, nb, stp);
     if (active) {
