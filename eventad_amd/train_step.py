@@ -323,7 +323,9 @@ class TrainStep:
         n = max(2, n)
         if n > 2 and not d["masked"]:
             # More than two chains without the CU partition (every stream on the whole chip): at 32 M events a run in this
-            # mode ended in a GPU memory fault whose cause is not established.  Refused at every size until it is.
+            # mode once ended in a GPU memory fault.  A cause that fits was found and fixed since (the chains' mask buffers
+            # were freed while their graphs still wrote them; see add_chain), but the mode has not been run again -- it has
+            # no use where two chains already hide a small head -- so it stays refused at every size.
             raise RuntimeError("TrainStep: %d backbone chains need the CU-partitioned head (EVENTAD_HEAD_CUS > 0, or a head that "
                                "takes more than 0.3 of its backbone's time); without it at most 2 chains are allowed" % n)
         while len(d["gb"]) < n:
