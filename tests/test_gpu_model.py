@@ -248,7 +248,8 @@ def test_more_than_two_chains_without_the_cu_partition_are_refused():
 
 
 @pytest.mark.skip(reason="more than two backbone chains on unpartitioned (whole-chip) streams: a run of this mode at 32 M events "
-                         "faulted the GPU and the cause is not established; TrainStep.capture_dual refuses the mode")
+                         "once faulted the GPU; a cause that fits (mask buffers freed while their graphs wrote them) is "
+                         "fixed, but the mode has not been run since and TrainStep.capture_dual still refuses it")
 def test_three_and_four_unpartitioned_chains_equal_sequential_steps():
     import eventad_amd.compat as compat
     compat.install()

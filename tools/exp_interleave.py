@@ -13,8 +13,9 @@ dev = torch.device("cuda:0")
 graphs, keep = [], []
 NG = int(sys.argv[3]) if len(sys.argv) > 3 else 2           # graphs (= streams) in flight
 if NG > 2:
-    # three or more backbone passes in flight on whole-chip streams: a training run in that form at 32 M events ended in a GPU
-    # memory fault whose cause is not established (TrainStep.capture_dual refuses it too)
+    # three or more backbone passes in flight on whole-chip streams: a training run in that form at 32 M events once ended in a
+    # GPU memory fault (a likely cause in the training step's buffer handling is fixed; this form has not been run since and
+    # TrainStep.capture_dual refuses it too)
     raise SystemExit("exp_interleave: more than 2 concurrent backbone graphs on unpartitioned streams are refused")
 for i in range(NG):
     args, model, sd = bench.build_model(W, H, B, dev, live_cnn=live)
