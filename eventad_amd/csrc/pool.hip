@@ -329,10 +329,11 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
     unsigned bm0 = 0, bm1 = 0, bm2 = 0; bool bad = false;
     // one chunk: candidate r of this lane (have = the lane holds a candidate), count = candidates in the chunk
     auto chunk = [&](int r, bool have, int count) {
-        int off = 0, cmask = 0; float fx = 0.f, fy = 0.f;
+        int off = 0, cmask = 0; float fx = 0.f, fy = 0.f, px = 0.f, py = 0.f;
         if (have) {
             const int ns = node_slot[r];
-            const float px = posn_s[3 * r], py = posn_s[3 * r + 1], pt = posn_s[3 * r + 2];
+            px = posn_s[3 * r]; py = posn_s[3 * r + 1];
+            const float pt = posn_s[3 * r + 2];
             const int k = key_s[r], id = sid[r];
             if (ns == slot) {
                 ++n; sx += (unsigned)(k % W); sy += (unsigned)((k / W) % H);
@@ -346,22 +347,18 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
                 off = ((b * map_h + y0) * map_w + x0) * 64;   // float offset of the top-left corner (only used where valid)
             }
         }
-        const int iters = (count + 3) >> 2;
-#pragma unroll 2
-        for (int it = 0; it < iters; ++it) {
-            const int m = it * 4 + grp;                      // < 64 whenever it < iters
-            const int m_r = __shfl(r, m, 64), m_mask = __shfl(cmask, m, 64), m_off = __shfl(off, m, 64);
-            const float m_fx = __shfl(fx, m, 64), m_fy = __shfl(fy, m, 64);
+        // the map sample of member m (a lane of this chunk; m < 0: none): channels 4q .. 4q+3 into the running maximum
+        auto sample = [&](int m) {
+            const int mm = max(m, 0);
+            const int m_mask_l = __shfl(cmask, mm, 64), m_off = __shfl(off, mm, 64);     // (every lane takes part in the shuffles)
+            const int m_mask = m >= 0 ? m_mask_l : 0;
+            const float m_fx = __shfl(fx, mm, 64), m_fy = __shfl(fy, mm, 64);
             const bool ok = (m_mask & 16) != 0;
-            const int rr = ok ? m_r : 0;
             const float* p00 = map + (ok ? m_off : 0) + 4 * q;
             const float4 c00 = *(const float4*)((m_mask & 1) ? p00 : map);
             const float4 c01 = *(const float4*)((m_mask & 2) ? p00 + 64 : map);
             const float4 c10 = *(const float4*)((m_mask & 4) ? p00 + (size_t)map_w * 64 : map);
             const float4 c11 = *(const float4*)((m_mask & 8) ? p00 + (size_t)map_w * 64 + 64 : map);
-            const float yv = y2[(size_t)rr * 16 + q];
-            int e_src = 0, e_deg = 0;
-            if (bitmap) { e_src = ell_src[(size_t)rr * 16 + q]; e_deg = deg[rr]; }
             const float w00 = (m_mask & 1) ? (1.f - m_fx) * (1.f - m_fy) : 0.f, w01 = (m_mask & 2) ? m_fx * (1.f - m_fy) : 0.f;
             const float w10 = (m_mask & 4) ? (1.f - m_fx) * m_fy : 0.f, w11 = (m_mask & 8) ? m_fx * m_fy : 0.f;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -369,10 +366,43 @@ __global__ __launch_bounds__(256) void k_pool_seg0(
             v.x += c01.x * w01; v.y += c01.y * w01; v.z += c01.z * w01; v.w += c01.w * w01;
             v.x += c10.x * w10; v.y += c10.y * w10; v.z += c10.z * w10; v.w += c10.w * w10;
             v.x += c11.x * w11; v.y += c11.y * w11; v.z += c11.z * w11; v.w += c11.w * w11;
-            if (ok) {
-                mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-                my = fmaxf(my, yv);
+            if (ok) { mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w); }
+        };
+        // Members at the same position as the member in the lane before them (several events of one pixel: they are
+        // neighbours in the pixel-sorted array) have the same sample, and a maximum does not care how often it sees a value:
+        // at two or more events per pixel most samples are such repeats.  A chunk in which a third or more of the
+        // members are repeats samples its distinct positions in a loop of its own; the others (the sparse case) keep
+        // sample and row in one loop.
+        const bool member = (cmask & 16) != 0;
+        const float ppx = __shfl_up(px, 1, 64), ppy = __shfl_up(py, 1, 64);
+        const int pmask = __shfl_up(cmask, 1, 64);
+        const bool repeat = member && lane > 0 && (pmask & 16) && ppx == px && ppy == py;
+        unsigned long long distinct = __ballot(member && !repeat);
+        const bool split = 3 * __popcll(__ballot(repeat)) >= __popcll(__ballot(member)) && __ballot(repeat) != 0ull;   // a third or more
+        if (split) {
+            while (distinct) {
+                int m = -1;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {             // group g4 takes the g4-th lowest lane of the set (scalar unit)
+                    const int mk = distinct ? __ffsll((long long)distinct) - 1 : -1;
+                    distinct &= distinct - 1ull;             // (clearing a bit of 0 leaves 0)
+                    m = grp == g4 ? mk : m;
+                }
+                sample(m);
             }
+        }
+        const int iters = (count + 3) >> 2;
+#pragma unroll 2
+        for (int it = 0; it < iters; ++it) {
+            const int m = it * 4 + grp;                      // < 64 whenever it < iters
+            const int m_r = __shfl(r, m, 64), m_mask = __shfl(cmask, m, 64);
+            const bool ok = (m_mask & 16) != 0;
+            const int rr = ok ? m_r : 0;
+            const float yv = y2[(size_t)rr * 16 + q];
+            int e_src = 0, e_deg = 0;
+            if (bitmap) { e_src = ell_src[(size_t)rr * 16 + q]; e_deg = deg[rr]; }
+            if (!split) sample(m);
+            if (ok) my = fmaxf(my, yv);
             if (bitmap && ok && q >= 1 && q < e_deg) {
                 const int vs = node_vox[e_src];
                 const int dx = (vs & 255) - cx, dy = ((vs >> 8) & 255) - cy, dp = (vs >> 16) - plane;
