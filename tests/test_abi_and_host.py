@@ -27,6 +27,14 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.eventad_insert_in_queue(None, None, None, None, 1, 1, 1, 1, 1, None) == -1
     assert lib.eventad_gemm_f32(None, 4, None, 4, None, 4, 1, None, 1, 1, None, None, None, None, 0, 0, None) == -1
     assert lib.eventad_roi_pool(None, None, None, None, 0, None, None, 0, 0, 2, 64, 64, 1, None, None) == -1
+    # entry points added for the pooled levels' live-cell products, the asynchronous update and the dropout masks
+    assert lib.eventad_tail_live_cells(None, None, None, 8, 1.0, 1.0, None, 1, None) == -1
+    assert lib.eventad_tail_gemm(None, 84, None, 1728, None, 1728, 64, None, 1728, 84, None, None) == -1
+    assert lib.eventad_incr_reset(None, 16, None) == -1
+    assert lib.eventad_incr_edges(None, None, None, None, None, None, 0, 1, 0, 8, 8, 3, 1000, 16, 8, None, None, None, None) == -1
+    assert lib.eventad_dropout_masks(None, 16, 0.7, 1, 0, None, None) == -1
+    assert lib.eventad_conv2d_workspace_floats(1, 8, 8, 16, 16, 3, 3, None) == -1
+    assert lib.eventad_clip_adamw(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None, None, None) == -1
 
 
 def test_spiral_table_matches_oracle():
