@@ -22,7 +22,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LDS_CLOCK_GHZ = 2.4            # MI355X peak engine clock (MI355X_MICROARCH.md): LDS peak = 128 B per clock and CU
+ENGINE_CLOCK_GHZ = 2.4         # MI355X peak engine clock (MI355X_MICROARCH.md)
+LDS_B128_BYTES_PER_CLK = 256   # per CU, ds_read_b128 (MI355X_MICROARCH.md, LDS table)
+VALU_FMA_PER_CLK = 64          # per CU: 4 SIMDs x 16 lanes, one fp32 FMA per lane and clock (packed fp32 is off in this build)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak 6290 GB/s
 # C-ABI call -> prefixes of the kernel names it launches, as they appear in the rocprofv3 traces / profiles/*_hbm_traffic.json
 # (the template arguments depend on the configuration: row scan or spiral walk, LUT fully or partly in LDS)
@@ -243,13 +245,21 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": name.split("#")[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                                "algorithmic_bytes": ab[name], "avg_launch_ms": round(ms, 4)}
-            lds_per_edge = {"eventad_l1_conv1#1": 1280, "eventad_l1_conv2#1": 1024}.get(name)
-            if lds_per_edge:
-                # What holds the layer-1 convolutions is the LDS, not the HBM: an edge's 4 lanes read its Cin x 16 weight
-                # matrix from the LUT in LDS once (Cin ds_read_b128 per lane), 128 B per clock and CU.
-                peak = 128.0 * torch.cuda.get_device_properties(0).multi_processor_count * LDS_CLOCK_GHZ
-                lds = lds_per_edge * E / (ms * 1e-3) / 1e9
-                out["roofline"]["lds"] = {"bytes_per_edge": lds_per_edge, "achieved": round(lds, 1), "peak": round(peak, 1),
+            cin = {"eventad_l1_conv1#1": 20, "eventad_l1_conv2#1": 16}.get(name)
+            if cin:
+                # What holds the layer-1 convolutions is neither HBM nor LDS but the vector ALU: an edge multiplies its source
+                # row by ITS cell's Cin x 16 matrix, Cin*16 fp32 FMAs that no other edge shares (v_fma_f32, one per lane and
+                # clock: this build does not use the packed form).  The same edge reads the matrix from LDS once, Cin
+                # ds_read_b128 per lane of its quad = Cin*64 bytes, against 256 B per clock and CU.
+                cus = torch.cuda.get_device_properties(0).multi_processor_count
+                peak_tf = 2.0 * VALU_FMA_PER_CLK * cus * ENGINE_CLOCK_GHZ / 1e3
+                tf = 2.0 * cin * 16 * E / (ms * 1e-3) / 1e12
+                out["roofline"]["valu"] = {"flop_per_edge": 2 * cin * 16, "achieved": round(tf, 2), "peak": round(peak_tf, 1),
+                                           "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4),
+                                           "peak_note": "non-packed v_fma_f32; the spec's 157.3 TFLOP/s counts v_pk_fma_f32"}
+                peak = float(LDS_B128_BYTES_PER_CLK) * cus * ENGINE_CLOCK_GHZ
+                lds = cin * 64 * E / (ms * 1e-3) / 1e9
+                out["roofline"]["lds"] = {"bytes_per_edge": cin * 64, "achieved": round(lds, 1), "peak": round(peak, 1),
                                           "unit": "GB/s", "frac": round(lds / peak, 4)}
             out["stage_ms"] = {k.replace("eventad_", ""): round(v[1], 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:12]}
             out["backbone_ms"] = round(sum(v[1] for v in summ.values()), 4)

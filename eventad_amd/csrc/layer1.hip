@@ -17,8 +17,9 @@
 // i < 4 and channel 16+j for i = 4), see eventad_amd/spline.py::quad_row_order.
 //
 // Mapping (64-lane waves, 16 destinations per pass, no workgroup barrier after the LUT is staged):
-//  * 64 consecutive destinations are ranked by degree with ballots and split into 4 passes of 16 destinations of (nearly)
-//    equal degree -- a wave pays for the longest row of a pass; a wave takes work items of 1 or 2 such passes from a per-XCD
+//  * 64 consecutive destinations are ranked by degree class (ceil(degree / 2)) with ballots and split into 4 passes of 16
+//    destinations of (nearly) equal degree -- a wave pays for the longest row of a pass, in blocks of 4 slots or half a block;
+//    a wave takes work items of 1 or 2 such passes from a per-XCD
 //    work counter (dynamic: items differ several times in edge count, and a wave's last item is the kernel's tail);
 //  * lane j of a destination's quad owns input channels {4j..4j+3} (+ channel 16+j when Cin = 20): a neighbour row
 //    costs one 16-byte (+ one 4-byte) load per lane, each byte of the row fetched once per quad, and only 4-5 registers;
@@ -42,12 +43,21 @@
 template <typename T> __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) {
     return *(const T*)((const char*)base + byte_off);
 }
+// (x << SH) + y in one full-rate instruction.  Written as asm because the compiler turns shift-and-add chains back into
+// a 32-bit multiply (v_mul_lo_u32 / v_mad_u64_u32), which issues at a quarter of the rate.
+template <int SH> __device__ __forceinline__ unsigned lshl_add(unsigned x, unsigned y) {
+    unsigned r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(SH), "v"(y));
+    return r;
+}
+// j16 = 16 * j, je = 64 - 12 * j (byte offsets of the lane's 16-byte piece and, from there, of its channel 16 + j)
 template <int CINP>
-__device__ __forceinline__ void l1_load_row(const float* __restrict__ xin, int src, int j, float4& v, float& e) {
-    const unsigned o = (unsigned)src * (CINP * 4u) + 16u * (unsigned)j;
+__device__ __forceinline__ void l1_load_row(const float* __restrict__ xin, int src, unsigned j16, unsigned je, float4& v, float& e) {
+    // row bytes: 64 (16 channels) or 80 = 64 + 16 (20 channels)
+    const unsigned o = CINP == 20 ? lshl_add<6>((unsigned)src, lshl_add<4>((unsigned)src, j16)) : lshl_add<6>((unsigned)src, j16);
     v = ld_off<float4>(xin, o);
     e = 0.f;
-    if (CINP == 20) e = ld_off<float>(xin, (unsigned)src * 80u + 64u + 4u * (unsigned)j);
+    if (CINP == 20) e = ld_off<float>(xin, o + je);
 }
 
 __device__ __forceinline__ float quad_sum(float v) {
@@ -56,24 +66,76 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
-// acc[s] += x * W[chunk (s+a)&3] for the KL channels of this lane; wl = row of this lane's channel 0 (rows are stored
-// [i][j], 16 floats each, so channel i is 64 floats further)
+// acc[s] += x * W[chunk (s+a)&3] for the KL channels of this lane, the matrix read from global memory: base = a uniform
+// pointer, ad[s] = byte offset of the lane's chunk s in the matrix's first row for this lane (rows are stored [i][j], 16
+// floats each, so channel i is 256 bytes further).
 template <int KL>
-__device__ __forceinline__ void l1_fma(float4 (&acc)[4], const float4& xv, float xe, const float* __restrict__ wl,
-                                       const int (&rot)[4]) {
+__device__ __forceinline__ void l1_fma_glb(float4 (&acc)[4], const float4& xv, float xe, const char* __restrict__ base,
+                                           const unsigned (&ad)[4]) {
     const float xs[5] = {xv.x, xv.y, xv.z, xv.w, xe};
+    // One channel's four chunks are requested while the previous channel's products run: two channels' weights (8 x 16 bytes =
+    // 32 registers) in flight, and no more -- unbounded hoisting of the 20 reads of an edge, and of the next edge's, runs the
+    // kernel out of registers, and a spill's scratch traffic shares vmcnt with the prefetched rows.  The channel's 256 bytes
+    // go to the uniform base, so that they end up in the load's immediate offset.
+    float4 w[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[0][s] = ld_off<float4>(base, ad[s]);
 #pragma unroll
     for (int i = 0; i < KL; ++i) {
+        if (i + 1 < KL) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w[(i + 1) & 1][s] = ld_off<float4>(base + (i + 1) * 256, ad[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const float4 w = *(const float4*)(wl + i * 64 + rot[s]);
-            acc[s].x = fmaf(xs[i], w.x, acc[s].x); acc[s].y = fmaf(xs[i], w.y, acc[s].y);
-            acc[s].z = fmaf(xs[i], w.z, acc[s].z); acc[s].w = fmaf(xs[i], w.w, acc[s].w);
+            const float4 v = w[i & 1][s];
+            acc[s].x = fmaf(xs[i], v.x, acc[s].x); acc[s].y = fmaf(xs[i], v.y, acc[s].y);
+            acc[s].z = fmaf(xs[i], v.z, acc[s].z); acc[s].w = fmaf(xs[i], v.w, acc[s].w);
         }
-        // at most two channels' weights (8 x ds_read_b128 = 32 registers) in flight: unbounded hoisting of the 20 reads of an
-        // edge -- and of the next edge's -- runs the kernel out of registers, and a spill's scratch traffic shares vmcnt
-        // with the prefetched rows
-        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The same for a matrix in LDS, addressed in bytes: ad[s] = the lane's chunk (s + a) & 3 of the matrix's first row for this
+// lane (one multiply-add per chunk and edge, see l1_edge); channel i is 256 bytes further (an immediate offset).
+template <int KL, bool PIPE>
+__device__ __forceinline__ void l1_fma_lds(float4 (&acc)[4], const float4& xv, float xe, const float* __restrict__ smem0,
+                                           const unsigned (&ad)[4]) {
+    const float xs[5] = {xv.x, xv.y, xv.z, xv.w, xe};
+    if (PIPE) {
+        // one channel's four chunks are requested while the previous channel's products run (two channels = 32 registers in
+        // flight); the scheduling barriers keep that order
+        float4 w[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w[0][s] = *(const float4*)((const char*)smem0 + ad[s]);
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            if (i + 1 < KL) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) w[(i + 1) & 1][s] = *(const float4*)((const char*)smem0 + ad[s] + (i + 1) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 v = w[i & 1][s];
+                acc[s].x = fmaf(xs[i], v.x, acc[s].x); acc[s].y = fmaf(xs[i], v.y, acc[s].y);
+                acc[s].z = fmaf(xs[i], v.z, acc[s].z); acc[s].w = fmaf(xs[i], v.w, acc[s].w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // (the instantiations that also carry the global-memory branch have no registers for two channels in flight)
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 v = *(const float4*)((const char*)smem0 + ad[s] + i * 256);
+                acc[s].x = fmaf(xs[i], v.x, acc[s].x); acc[s].y = fmaf(xs[i], v.y, acc[s].y);
+                acc[s].z = fmaf(xs[i], v.z, acc[s].z); acc[s].w = fmaf(xs[i], v.w, acc[s].w);
+            }
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -94,10 +156,18 @@ template <int S> __device__ __forceinline__ int comp4(const int4& v) { return S 
 // multiply a cached row (the destination's own) by the all-zero matrix LUT[steps + 1] instead.
 template <int CINP, int KL, int S, bool ALL_IN_LDS>
 __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float (&xe)[4], const int4& sv, const uint2& cv,
-                                        const int4& sv2, int b, bool last, bool half, int d, int d2, int j, int safe, int safe2,
-                                        const float* __restrict__ xin, const float* __restrict__ wlds, const float* __restrict__ wglb,
-                                        int nlds, const int (&rot)[4], int steps) {
+                                        const int4& sv2, int b, bool last, bool half, int d, int d2, unsigned j16, unsigned je,
+                                        int safe, int safe2, const float* __restrict__ xin, const float* __restrict__ smem0,
+                                        const unsigned (&lbase)[4], const char* __restrict__ lutg,
+                                        int nlds, int steps) {
     constexpr int LS = CINP * 16;
+    // byte address of chunk s of matrix `c` in the LDS table (and, from `lutg`, in the table in global memory): a 24-bit
+    // multiply (full rate; cells and LS * 4 are far below 2^24) and one add per chunk
+    auto mat_addr = [&](int c, unsigned (&ad)[4]) {
+        const unsigned m = __umul24((unsigned)c, (unsigned)(LS * 4));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ad[s] = m + lbase[s];
+    };
     const int e = 4 * b + S;
     const int pair = quad_bcast<0>((int)(S & 2 ? cv.y : cv.x));
     int cell = (S & 1) ? (int)((unsigned)pair >> 16) : (pair & 0xffff);
@@ -110,18 +180,19 @@ __device__ __forceinline__ void l1_edge(float4 (&acc)[4], float4 (&xv)[4], float
     const int src = last ? nnext : nsrc;
     // `half` (uniform): the row's last block holds at most two live slots -- slots 2 and 3 only refill their buffers
     if (S < 2 || !half) {
-        if (ALL_IN_LDS) l1_fma<KL>(acc, xv[S], xe[S], wlds + cell * LS, rot);
+        unsigned ad[4];
+        if (ALL_IN_LDS) { mat_addr(cell, ad); l1_fma_lds<KL, true>(acc, xv[S], xe[S], smem0, ad); }
         else {
             // Large search radius: only the first `nlds` spiral steps (the inner rings, where the <= 16 neighbours of a dense
             // window lie) + the two special matrices are in LDS.  A slot in which ANY lane of the wave needs an outer ring
             // reads its matrices from global memory (L2) for the whole wave -- rare, and wave-uniform, so no lane diverges.
             const bool outer = cell >= nlds && cell < steps;
-            if (__any(outer)) l1_fma<KL>(acc, xv[S], xe[S], wglb + (size_t)cell * LS, rot);
-            else              l1_fma<KL>(acc, xv[S], xe[S], wlds + (cell < nlds ? cell : nlds + cell - steps) * LS, rot);
+            if (__any(outer)) { mat_addr(cell, ad); l1_fma_glb<KL>(acc, xv[S], xe[S], lutg, ad); }
+            else { mat_addr(cell < nlds ? cell : nlds + cell - steps, ad); l1_fma_lds<KL, true>(acc, xv[S], xe[S], smem0, ad); }
         }
     }
     // the refill comes after the products that read the buffer, so the old row needs no copy
-    l1_load_row<CINP>(xin, src, j, xv[S], xe[S]);
+    l1_load_row<CINP>(xin, src, j16, je, xv[S], xe[S]);
 }
 
 template <int CINP, bool SKIP, bool ALL_IN_LDS, int THREADS, bool BY_TAIL>
@@ -147,12 +218,17 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     if (SKIP) { if (tid < 80) ((float4*)s_skip)[tid] = ((const float4*)wskip)[tid]; }
     __syncthreads();                                      // the only workgroup barrier: from here on every wave is on its own
     const int lane = tid & 63, j = lane & 3, q = lane >> 2, a = q & 3;
-    int rot[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) rot[s] = ((s + a) & 3) * 4;
     const float4 sh = *(const float4*)(shift + 4 * j);
-    const float* wlds = s_lut + j * 16;
-    const float* wglb = lut + j * 16;
+    // per-lane byte offsets, kept in registers (opaque to the compiler, which would otherwise rebuild them from j and a with
+    // shifts at every use): the lane's piece of a row, its channel 16 + j from there, and lbase[s] = where the lane's chunk
+    // (s + a) & 3 of a matrix's first row for this lane lies in the LDS table's first matrix
+    constexpr unsigned LUT_OFF = SKIP ? 20 * 16 * 4 : 0;  // the table's byte offset in LDS
+    unsigned j16 = 16u * (unsigned)j, je = 64u - 12u * (unsigned)j;
+    unsigned lbase[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) lbase[s] = LUT_OFF + 64u * (unsigned)j + 16u * (unsigned)((s + a) & 3);
+    asm volatile("" : "+v"(j16), "+v"(je), "+v"(lbase[0]), "+v"(lbase[1]), "+v"(lbase[2]), "+v"(lbase[3]));
+    const char* lutg = (const char*)lut - LUT_OFF;        // the same offsets address the table in global memory from here
     constexpr bool by_tail = BY_TAIL;                     // rank the rows of a group by their outer tail, see below (the host's choice)
     static_assert(!(BY_TAIL && ALL_IN_LDS), "a table that is resident as a whole has no outer tail");
     // Work items: groups of 64 consecutive destinations, handed out by one counter per XCD (blockIdx & 7: workgroups are dealt
@@ -174,19 +250,23 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
         if (lane == 0) v = atomicAdd(ctr, 1u);
         return (int)__builtin_amdgcn_readfirstlane(v);
     };
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int item = fetch();
     while (item < nitems) {
         const int inext = fetch();                        // its round trip overlaps this item's work
         const int g = gbeg + item / IPG, p0 = (item % IPG) * L1_ITEM_PASSES;
         const int n0 = n_first + g * L1_GROUP;
-        // rank the 64 destinations by degree (descending; ties by lane) with 17 ballots, then invert the ranking
+        // rank the 64 destinations by degree class (descending; ties by lane) with 9 ballots, then invert the ranking.  A pass
+        // costs whole blocks of 4 slots, or half a block for 1-2 slots, so degrees 2c - 1 and 2c cost the same and need not be
+        // told apart: the passes' costs are those of an exact ranking, at half the ballots.
         const int d_l = n0 + lane < N ? min(ld_off<int>(deg, 4u * (unsigned)(n0 + lane)), 16) : 0;
+        const int c_l = (d_l + 1) >> 1;
         int rank = 0, base = 0;
 #pragma unroll
-        for (int v = 16; v >= 0; --v) {
-            const unsigned long long m = __ballot(d_l == v);
-            if (d_l == v) rank = base + __popcll(m & lt_mask);
+        for (int v = 8; v >= 0; --v) {
+            const unsigned long long m = __ballot(c_l == v);
+            // base + number of lower lanes in the class (v_mbcnt_lo / v_mbcnt_hi: two instructions)
+            const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
+            if (c_l == v) rank = r;
             base += __popcll(m);
         }
         if (by_tail) {
@@ -212,7 +292,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
 #pragma unroll
             for (int v = 16; v >= 0; --v) {
                 const unsigned long long m = __ballot(f_r == v);
-                if (f_r == v) rank2 = base2 + __popcll(m & lt_mask);
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base2));
+                if (f_r == v) rank2 = r;
                 base2 += __popcll(m);
             }
             rank = __builtin_amdgcn_ds_bpermute(rank << 2, rank2);           // this row's place in the final order
@@ -228,13 +309,14 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
             const int s0 = quad_bcast<0>(sv.x), s1 = quad_bcast<0>(sv.y), s2 = quad_bcast<0>(sv.z), s3 = quad_bcast<0>(sv.w);
             const int first[4] = {s0, s1, s2, s3};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d ? first[u] : safe, j, xv[u], xe[u]);
+            for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d ? first[u] : safe, j16, je, xv[u], xe[u]);
         }
 #pragma unroll 1
         for (int p = p0; p < p0 + L1_ITEM_PASSES; ++p) {
             int dmax;
             if (!by_tail) {
-                dmax = __builtin_amdgcn_readfirstlane(d);                  // ranked by degree: quad 0 of the pass has the longest row
+                // ranked by degree class: quad 0 of the pass is in the pass's highest class, whose upper end bounds every row
+                dmax = (__builtin_amdgcn_readfirstlane(d) + 1) & ~1;
                 if (dmax == 0) break;                                      // ... and the passes after an empty one are empty
             } else {                                                       // ranked by the outer tail first: any quad may
                 int m = d;
@@ -256,20 +338,20 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
                 const int t0 = quad_bcast<0>(sv2.x), t1 = quad_bcast<0>(sv2.y), t2 = quad_bcast<0>(sv2.z), t3 = quad_bcast<0>(sv2.w);
                 const int nxt[4] = {t0, t1, t2, t3};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d2 ? nxt[u] : safe2, j, xv[u], xe[u]);
+                for (int u = 0; u < 4; ++u) l1_load_row<CINP>(xin, u < d2 ? nxt[u] : safe2, j16, je, xv[u], xe[u]);
             }
             // the destination's own input row for the skip branch: requested ahead of the edge loop, except in the one
             // instantiation where holding it across the loop costs spills (there it is loaded when it is needed)
             constexpr bool LATE_SKIP = SKIP && !ALL_IN_LDS && !BY_TAIL;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f); float ke = 0.f;
-            if (SKIP && !LATE_SKIP) l1_load_row<20>(xskip, safe, j, kv, ke);
+            if (SKIP && !LATE_SKIP) l1_load_row<20>(xskip, safe, j16, je, kv, ke);
             float4 acc[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
             for (int b = 0; 4 * b < dmax; ++b) {
                 const bool last = 4 * (b + 1) >= dmax, half = dmax - 4 * b <= 2;
-#define L1_E(S) l1_edge<CINP, KL, S, ALL_IN_LDS>(acc, xv, xe, sv, cv, sv2, b, last, half, d, d2, j, safe, safe2, xin, wlds, wglb, nlds, rot, steps)
+#define L1_E(S) l1_edge<CINP, KL, S, ALL_IN_LDS>(acc, xv, xe, sv, cv, sv2, b, last, half, d, d2, j16, je, safe, safe2, xin, smem, lbase, lutg, nlds, steps)
                 L1_E(0); L1_E(1); L1_E(2); L1_E(3);
 #undef L1_E
                 sv.x = quad_rotate(sv.x); sv.y = quad_rotate(sv.y); sv.z = quad_rotate(sv.z); sv.w = quad_rotate(sv.w);
@@ -284,10 +366,11 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
             int skip_on = 1;
             asm volatile("" : "+s"(skip_on));
             if (SKIP && (BY_TAIL || skip_on)) {
-                if (LATE_SKIP) l1_load_row<20>(xskip, safe, j, kv, ke);
-                int sk = j * 16;
+                if (LATE_SKIP) l1_load_row<20>(xskip, safe, j16, je, kv, ke);
+                unsigned sk = 0u - LUT_OFF;               // (the skip matrix lies at the start of LDS, in the table's row order)
                 asm volatile("" : "+v"(sk));              // opaque: or the 20 loop-invariant weight reads are hoisted out of
-                l1_fma<5>(acc, kv, ke, s_skip + sk, rot); // every loop and held in 80 registers for the kernel's lifetime
+                const unsigned ad[4] = {lbase[0] + sk, lbase[1] + sk, lbase[2] + sk, lbase[3] + sk};   // every loop and held in
+                l1_fma_lds<5, false>(acc, kv, ke, smem, ad);                                           // 80 registers for the kernel's lifetime
             }
             // reduce the partial sums over the quad; lane j keeps output chunk j, which sits in accumulator (j - a) & 3
             float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
