@@ -208,16 +208,27 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     float* s_skip = smem;                                 // [5][4][16] (SKIP only)
     float* s_lut = s_skip + (SKIP ? 20 * 16 : 0);         // [nlds+2][KL][4][16]: spiral steps 0..nlds-1, self-edge matrix, zeros
     const int tid = threadIdx.x;
-    // ---- once per workgroup: LUT and skip weights (already in the [i][j][16] row order) into LDS, 16 bytes per lane and trip
+    const int lane = tid & 63, j = lane & 3, q = lane >> 2, a = q & 3;
+    // ---- once per workgroup: LUT and skip weights (already in the [i][j][16] row order) into LDS.  The table goes there
+    //      directly (global_load_lds_dwordx4: a wave-instruction writes 64 x 16 bytes to a wave-uniform LDS address, no
+    //      registers in between), every piece requested at once -- a load -> wait -> ds_write loop paid one L2 round trip per
+    //      trip, 8 to 10 of them.
+    const int xcd = blockIdx.x & 7;
+    unsigned* ctr = work + 32 * xcd;                      // one 128-byte line per XCD: counters sharing a line serialise like one word
     {
         const float4* g4 = (const float4*)lut;
-        float4* s4 = (float4*)s_lut;
-        const int n4 = nlds * LS / 4, m4 = 2 * LS / 4, skip4 = (steps - nlds) * LS / 4;
-        for (int t = tid; t < n4 + m4; t += THREADS) s4[t] = g4[t < n4 ? t : t + skip4];
+        const int n4 = nlds * LS / 4, m4 = 2 * LS / 4, skip4 = (steps - nlds) * LS / 4, tot = n4 + m4;
+        constexpr int TRIPS = 10, WAVES = THREADS / 64;   // the host checks that this covers the table: 80 KiB / (512 x 16 B), 152 KiB / (1024 x 16 B)
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int u = 0; u < TRIPS; ++u) {
+            const int piece = u * WAVES + wv, t = piece * 64 + lane;         // 1 KiB pieces, dealt round-robin to the waves
+            if (t < tot)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g4 + (t < n4 ? t : t + skip4)),
+                                                 (__attribute__((address_space(3))) void*)((char*)s_lut + piece * 1024), 16, 0, 0);
+        }
     }
     if (SKIP) { if (tid < 80) ((float4*)s_skip)[tid] = ((const float4*)wskip)[tid]; }
-    __syncthreads();                                      // the only workgroup barrier: from here on every wave is on its own
-    const int lane = tid & 63, j = lane & 3, q = lane >> 2, a = q & 3;
     const float4 sh = *(const float4*)(shift + 4 * j);
     // per-lane byte offsets, kept in registers (opaque to the compiler, which would otherwise rebuild them from j and a with
     // shifts at every use): the lane's piece of a row, its channel 16 + j from there, and lbase[s] = where the lane's chunk
@@ -234,7 +245,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     // Work items: groups of 64 consecutive destinations, handed out by one counter per XCD (blockIdx & 7: workgroups are dealt
     // round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so the
     // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
-    const int xcd = blockIdx.x & 7;
     // Passes per work item.  A wave's last item is the kernel's tail, and items differ several times in edge count, so small
     // items balance better -- but every item of a group repeats the group's ranking.  Measured: one pass per item wins where
     // passes are uneven or long (tail-ranked 1280x720: conv1 3.04 -> 2.61 ms, conv2 1.95 -> 1.81; conv1 at 640x480: 8.6 ->
@@ -244,13 +254,20 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     // destinations [n_first, N): the whole node array, or the rows appended by an incremental update
     const int ngroups = (N - n_first + L1_GROUP - 1) / L1_GROUP, g8 = (ngroups + 7) >> 3;
     const int gbeg = xcd * g8, nitems = (min(gbeg + g8, ngroups) - gbeg) * IPG;
-    unsigned* ctr = work + 32 * xcd;                      // one 128-byte line per XCD: counters sharing a line serialise like one word
+    // A wave's first item is its own number among the XCD's waves (the grid is a multiple of 8 workgroups): no round trip
+    // before the first row, and no burst of one request per wave on the eight counters when the kernel starts; the counter
+    // hands out the items after those.
+    const int waves_xcd = (int)(gridDim.x >> 3) * (THREADS / 64);
     auto fetch = [&]() {
         unsigned v = 0;
         if (lane == 0) v = atomicAdd(ctr, 1u);
-        return (int)__builtin_amdgcn_readfirstlane(v);
+        return waves_xcd + (int)__builtin_amdgcn_readfirstlane(v);
     };
-    int item = fetch();
+    int item = (int)(blockIdx.x >> 3) * (THREADS / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The only workgroup barrier -- table complete -- is passed right before a wave's first read of the table, i.e. after its
+    // first item's dependent loads (degrees -> ELL row -> neighbour rows) are under way; a wave without items passes it at
+    // the end.  Every wave executes exactly one of the two (the conditions are wave-uniform); from there on it is on its own.
+    bool staged = false;
     while (item < nitems) {
         const int inext = fetch();                        // its round trip overlaps this item's work
         const int g = gbeg + item / IPG, p0 = (item % IPG) * L1_ITEM_PASSES;
@@ -348,6 +365,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
             float4 acc[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!staged) { __syncthreads(); staged = true; }
 #pragma unroll 1
             for (int b = 0; 4 * b < dmax; ++b) {
                 const bool last = 4 * (b + 1) >= dmax, half = dmax - 4 * b <= 2;
@@ -388,6 +406,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
         }
         item = inext;
     }
+    if (!staged) __syncthreads();
 }
 
 template <int CINP, bool SKIP>
@@ -407,6 +426,7 @@ static int launch_l1(const float* xin, const int* ell_src, const uint16_t* ell_s
     const size_t lds = fixed + sizeof(float) * (size_t)(nlds + 2) * LS;
     const int ngroups = (int)evad_blocks(N - n_first, L1_GROUP);
     const int threads = whole ? L1_THREADS : 2 * L1_THREADS, waves = threads / 64;
+    if ((size_t)(nlds + 2) * LS / 4 > (size_t)10 * threads) return EVAD_ERR_ARG;    // the kernel stages the table in 10 trips of 16 bytes per lane
     int wgs = (ngroups + waves - 1) / waves;            // at least one workgroup per `waves` groups ...
     const int max_wg = whole ? L1_MAX_WG : L1_MAX_WG / 2;
     if (wgs > max_wg) wgs = max_wg;                     // ... at most 16 waves per CU: the waves pull groups until none is left
