@@ -214,7 +214,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     //      registers in between), every piece requested at once -- a load -> wait -> ds_write loop paid one L2 round trip per
     //      trip, 8 to 10 of them.
     const int xcd = blockIdx.x & 7;
-    unsigned* ctr = work + 32 * xcd;                      // one 128-byte line per XCD: counters sharing a line serialise like one word
     {
         const float4* g4 = (const float4*)lut;
         const int n4 = nlds * LS / 4, m4 = 2 * LS / 4, skip4 = (steps - nlds) * LS / 4, tot = n4 + m4;
@@ -242,9 +241,15 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     const char* lutg = (const char*)lut - LUT_OFF;        // the same offsets address the table in global memory from here
     constexpr bool by_tail = BY_TAIL;                     // rank the rows of a group by their outer tail, see below (the host's choice)
     static_assert(!(BY_TAIL && ALL_IN_LDS), "a table that is resident as a whole has no outer tail");
-    // Work items: groups of 64 consecutive destinations, handed out by one counter per XCD (blockIdx & 7: workgroups are dealt
-    // round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so the
-    // neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
+    // Work items: passes of groups of 64 consecutive destinations, handed out by one counter per XCD (blockIdx & 7: workgroups
+    // are dealt round-robin to the 8 XCDs).  The waves of one XCD walk ONE contiguous eighth of the pixel-sorted node array, so
+    // the neighbour rows they gather -- a few sensor rows up or down -- are mostly in that XCD's own L2.
+    // (Handing a wave a fixed share of the items up front instead wins where items are short -- 256x256: 64 / 58 us with two
+    // thirds of the items fixed against 73 / 66 -- and loses where they are long: the waves drift apart in the array and out
+    // of each other's cache lines, 1280x720: +10 % at half the items fixed, 640x480: +3 %.  What the fixed items saved at
+    // 256x256 was mostly the counter's round trip in front of every item's loads, see below.  Several counters per XCD, each
+    // with a share of its groups and its workgroups: 2 / 4 / 8 of them 65 / 65 / 66 us against 68 at 256x256, +1 / 3 / 5 % at
+    // 1280x720; requests for several items at a time: no gain.)
     // Passes per work item.  A wave's last item is the kernel's tail, and items differ several times in edge count, so small
     // items balance better -- but every item of a group repeats the group's ranking.  Measured: one pass per item wins where
     // passes are uneven or long (tail-ranked 1280x720: conv1 3.04 -> 2.61 ms, conv2 1.95 -> 1.81; conv1 at 640x480: 8.6 ->
@@ -254,22 +259,29 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
     // destinations [n_first, N): the whole node array, or the rows appended by an incremental update
     const int ngroups = (N - n_first + L1_GROUP - 1) / L1_GROUP, g8 = (ngroups + 7) >> 3;
     const int gbeg = xcd * g8, nitems = (min(gbeg + g8, ngroups) - gbeg) * IPG;
+    unsigned* ctr = work + 32 * xcd;                      // one 128-byte line per XCD: counters sharing a line serialise like one word
     // A wave's first item is its own number among the XCD's waves (the grid is a multiple of 8 workgroups): no round trip
-    // before the first row, and no burst of one request per wave on the eight counters when the kernel starts; the counter
-    // hands out the items after those.
+    // before the first row, and no burst of one request per wave on the eight counters when the kernel starts (requests to
+    // one address are served one after the other, at the memory side of the chip); the counter hands out the items after those.
     const int waves_xcd = (int)(gridDim.x >> 3) * (THREADS / 64);
-    auto fetch = [&]() {
-        unsigned v = 0;
-        if (lane == 0) v = atomicAdd(ctr, 1u);
-        return waves_xcd + (int)__builtin_amdgcn_readfirstlane(v);
-    };
     int item = (int)(blockIdx.x >> 3) * (THREADS / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned next_raw = 0;
     // The only workgroup barrier -- table complete -- is passed right before a wave's first read of the table, i.e. after its
     // first item's dependent loads (degrees -> ELL row -> neighbour rows) are under way; a wave without items passes it at
     // the end.  Every wave executes exactly one of the two (the conditions are wave-uniform); from there on it is on its own.
     bool staged = false;
     while (item < nitems) {
-        const int inext = fetch();                        // its round trip overlaps this item's work
+        // Every item requests the next one.  Loads return in order: a request issued at the top of the item would sit in
+        // front of the item's own first loads (degrees, ELL row, neighbour rows), and every wait for one of those would
+        // wait for the counter's answer as well (256x256: 74 / 64 us, against 69 / 59 us this way).  It is issued when the
+        // item's last pass has its loads under way (or after the passes, when they end early) and is waited for at the
+        // item's end.
+        bool request = true;
+        auto ask = [&]() {
+            next_raw = 0;
+            if (lane == 0) next_raw = atomicAdd(ctr, 1u);
+            request = false;
+        };
         const int g = gbeg + item / IPG, p0 = (item % IPG) * L1_ITEM_PASSES;
         const int n0 = n_first + g * L1_GROUP;
         // rank the 64 destinations by degree class (descending; ties by lane) with 9 ballots, then invert the ranking.  A pass
@@ -366,6 +378,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!staged) { __syncthreads(); staged = true; }
+            if (request && !more) ask();
 #pragma unroll 1
             for (int b = 0; 4 * b < dmax; ++b) {
                 const bool last = 4 * (b + 1) >= dmax, half = dmax - 4 * b <= 2;
@@ -404,7 +417,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_l1_conv(const float* __restrict_
             }
             safe = safe2; nl = nl2; d = d2; sv = sv2; cv = cv2;
         }
-        item = inext;
+        if (request) ask();                               // (the passes ended early)
+        item = waves_xcd + (int)__builtin_amdgcn_readfirstlane(next_raw);
     }
     if (!staged) __syncthreads();
 }
