@@ -332,21 +332,38 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) { a0[t] = *(const float4*)(a0p + 16 * t); a1[t] = *(const float4*)(a1p + 16 * t); }
     }
-    // ---- stage this workgroup's weight columns; row dots and attention weights of the three slots
+    // ---- stage this workgroup's weight columns; row dots and attention weights of the three slots.  All pieces of the
+    //      three slices (two per thread and slice, the second for the lower half of the threads) are requested before the
+    //      first is stored: written as a copy loop per slice, each trip became load -> wait for everything outstanding (the
+    //      A rows above included) -> store, six round trips one after the other.  A slice that is not live reads the first 16 bytes
+    //      of an operand that exists and stores nothing.
     {
         const float* Wp[3] = {S0.whh, S1.whh, S1.wih_x};
         const bool live[3] = {S0.present && S0.has_next, S1.present && S1.has_next, S1.present && S1.has_dx};
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            if (!live[p]) continue;
-            for (int idx = tid; idx < 768 * 2; idx += 1024) {
-                const int n = idx >> 1, half = idx & 1;
-                const float4 v = *(const float4*)(Wp[p] + (size_t)n * 256 + 8 * g + 4 * half);
-                float* d = &Bs[p][n][4 * half];
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        }
-        if (S2.present && S2.has_next && tid < 96) BsC[tid] = S2.whh[tid * 32 + g];
+        // (hn: the one operand every present slot has -- the weight pointers of a slice that is not live may be null -- and
+        // at least one slot is present)
+        const float* safe = S0.present ? S0.hn : (S1.present ? S1.hn : S2.hn);
+        const int n0 = tid >> 1, n1 = min((tid + 1024) >> 1, 767), half = tid & 1;
+        const bool second = tid < 512;
+        float4 v00, v01, v10, v11, v20, v21;
+#define HB_LD(P, N, ON) (*(const float4*)((ON) ? Wp[P] + (size_t)(N) * 256 + 8 * g + 4 * half : safe))
+        v00 = HB_LD(0, n0, live[0]); v01 = HB_LD(0, n1, live[0] && second);
+        v10 = HB_LD(1, n0, live[1]); v11 = HB_LD(1, n1, live[1] && second);
+        v20 = HB_LD(2, n0, live[2]); v21 = HB_LD(2, n1, live[2] && second);
+#undef HB_LD
+        float vc = 0.f;
+        const bool lc = S2.present && S2.has_next && tid < 96;
+        if (lc) vc = S2.whh[tid * 32 + g];
+        // (every value above is needed here: no load can be moved behind a store)
+        asm volatile("" : "+v"(v00.x), "+v"(v00.y), "+v"(v00.z), "+v"(v00.w), "+v"(v01.x), "+v"(v01.y), "+v"(v01.z), "+v"(v01.w),
+                          "+v"(v10.x), "+v"(v10.y), "+v"(v10.z), "+v"(v10.w), "+v"(v11.x), "+v"(v11.y), "+v"(v11.z), "+v"(v11.w),
+                          "+v"(v20.x), "+v"(v20.y), "+v"(v20.z), "+v"(v20.w), "+v"(v21.x), "+v"(v21.y), "+v"(v21.z), "+v"(v21.w), "+v"(vc));
+#define HB_ST(P, N, V, ON) if (ON) { float* d = &Bs[P][N][4 * half]; d[0] = V.x; d[1] = V.y; d[2] = V.z; d[3] = V.w; }
+        HB_ST(0, n0, v00, live[0]) HB_ST(0, n1, v01, live[0] && second)
+        HB_ST(1, n0, v10, live[1]) HB_ST(1, n1, v11, live[1] && second)
+        HB_ST(2, n0, v20, live[2]) HB_ST(2, n1, v21, live[2] && second)
+#undef HB_ST
+        if (lc) BsC[tid] = vc;
     }
     if (tid < 3 * NT) {
         const HbSlot& S = G.s[tid >> 5];
