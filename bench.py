@@ -194,7 +194,11 @@ def main():
         run = lambda: ts.step(data)
         if not a.no_kernel_timing:
             nb.timing = {}
-    for _ in range(min(a.warmup, 5) if use_graph else 0):      # untimed: the replayed graphs' first runs (cold caches, pipeline fill)
+    # untimed: the replayed graphs' first runs (cold caches, pipeline fill), and enough of them that the timed region does not
+    # start on a chip that idled through the capture (the clocks take some milliseconds of load to come up: without this a
+    # 20-step region reads 3-4 % slower than a 300-step one)
+    n_warm = int(os.environ.get("EVENTAD_BENCH_GRAPH_WARMUP", "40"))
+    for _ in range(n_warm if use_graph else 0):
         run()
     barrier()
     t0 = time.perf_counter()
@@ -228,6 +232,7 @@ def main():
                                    % (a.config, W, H, n_ev, "live ResNet-50 branch" if live else "precomputed CNN maps", B),
                        "global_batch": world * B, "events_per_batch_per_gpu": N, "realised_edges_per_gpu": E,
                        "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager",
+                       "untimed_graph_replays": n_warm if use_graph else 0,
                        "pipeline": ("none" if not pipelined else "backbone(k+1..k+%d) || head update(k): hipGraphs on event-coupled streams, %d backbone chains (own workspace set and stream each), backbone %d batch(es) ahead, head updates in order on one stream" % (ts._dual["n"] - 1, ts._dual["n"], ts._dual["prefetch"])),
                          "cu_partition": ("head graph on %d CUs of its own, backbone graph on the others (CU-masked default-priority streams)" % ((ts.head_cus if ts.head_cus > 0 else torch.cuda.get_device_properties(0).multi_processor_count // 8)) if (pipelined and ts._dual and ts._dual.get("masked")) else "none"),
                        "input": "device-resident batch, H2D copy excluded; every step runs the full backbone + head update on it; precomputed feature maps stored channels-last (NHWC in memory)",
