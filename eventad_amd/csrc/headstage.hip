@@ -46,7 +46,8 @@ __global__ __launch_bounds__(1024) void k_head_stage_fwd(HsGroup G) {
     float* s_al = s_part + 3 * NT;                                        // [3][32] attention weights
     int* s_v = (int*)(s_al + 3 * NT);                                     // [3][32] validity of the previous clip's tracks
     float (*Red)[NT][24] = (float (*)[NT][24])(s_al + 6 * NT);            // [13][32][24] partial products of the 13 MFMA waves
-    const int tid = threadIdx.x, k = tid >> 5, c = tid & 31, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+    const int tid = threadIdx.x, k = tid >> 5, c = tid & 31, lane = tid & 63, g = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // (a scalar: what is selected by it is read with scalar loads)
     const HsSlot& S0 = G.s[0]; const HsSlot& S1 = G.s[1]; const HsSlot& S2 = G.s[2];
     const bool a0 = S0.present && S0.hn_prev, a1 = S1.present && S1.hn_prev, a2 = S2.present && S2.hn_prev;
 
@@ -85,7 +86,10 @@ __global__ __launch_bounds__(1024) void k_head_stage_fwd(HsGroup G) {
     }
     if (S2.present) { if (a2) hnc = S2.hn_prev[k * 32 + c]; kpc = (a2 ? S2.s_prev : S2.s_cur)[k * 32 + c]; }
     // cell operands of phase C
-    const int c_slot = tid >> 8, c_kk = (tid & 255) >> 3, c_j = 8 * g + (tid & 7);
+    // (the slot of a thread of the cell phase is the same for its whole wave: as a scalar, the slot's descriptor is read with
+    // scalar loads from the kernel arguments; indexed per lane it becomes a vector load per field and a round trip of its own
+    // in front of every operand)
+    const int c_slot = min(__builtin_amdgcn_readfirstlane(tid >> 8), 2), c_kk = (tid & 255) >> 3, c_j = 8 * g + (tid & 7);
     float c_gi[3] = {0.f, 0.f, 0.f}, c_bh[3] = {0.f, 0.f, 0.f}, c_mask = 1.f;
     if (tid < 512 && G.s[c_slot].present) {
         const HsSlot& S = G.s[c_slot];
@@ -115,9 +119,9 @@ __global__ __launch_bounds__(1024) void k_head_stage_fwd(HsGroup G) {
 #pragma unroll
     for (int d = 16; d > 0; d >>= 1) { p0 += __shfl_xor(p0, d, 64); p1 += __shfl_xor(p1, d, 64); p2 += __shfl_xor(p2, d, 64); }
     if (c == 0) { s_part[k] = p0; s_part[NT + k] = p1; s_part[2 * NT + k] = p2; }
-    if (tid < 3 * NT) {
-        const HsSlot& S = G.s[tid >> 5];
-        s_v[tid] = (S.present && S.hn_prev) ? S.valid_prev[tid & 31] : 0;
+    if (wave < 3 && lane < NT) {                             // one wave per slot: the slot's descriptor is read with scalar loads
+        const HsSlot& S = G.s[wave];
+        s_v[wave * NT + lane] = (S.present && S.hn_prev) ? S.valid_prev[lane] : 0;
     }
     __syncthreads();
     if (wave < 3) {                                          // one wave per slot; both half-waves compute the same 32 values
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
     int* s_v = (int*)(s_al + 3 * NT);                                     // [3][32]
     float (*s_dw)[NT][8] = (float (*)[NT][8])(s_al + 6 * NT);             // [2][32][8]  ds * tanh(hn) of slots 0, 1
     float* s_dwc = (float*)(s_dw + 2);                                    // [32]        ... of slot 2
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // (a scalar: what is selected by it is read with scalar loads)
     const HbSlot& S0 = G.s[0]; const HbSlot& S1 = G.s[1]; const HbSlot& S2 = G.s[2];
 
     // ---- the first half of each MFMA wave's A rows is requested before anything else (it arrives while the weight slices
@@ -332,7 +337,26 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) { a0[t] = *(const float4*)(a0p + 16 * t); a1[t] = *(const float4*)(a1p + 16 * t); }
     }
-    // ---- stage this workgroup's weight columns; row dots and attention weights of the three slots.  All pieces of the
+    // ---- row dots and attention weights of the three slots, one wave per slot (the slot's descriptor is then read with
+    //      scalar loads): validity, attention weight and all 32 partial dots of a track are requested here, in front of the
+    //      weight slices, and added up behind them (8 partial dots at a time, after the slices, were five round trips in
+    //      front of the stage's first barrier)
+    const bool rowdots = wave < 3 && lane < NT;
+    float pv[HS_WGS], rd_al = 0.f; int rd_v = 0; bool rd_next = false;
+#pragma unroll
+    for (int q = 0; q < HS_WGS; ++q) pv[q] = 0.f;
+    if (rowdots) {
+        const HbSlot& S = G.s[wave];
+        if (S.present) {
+            rd_v = S.valid[lane]; rd_al = S.alpha[lane];
+            if (S.has_next) {
+                rd_next = true;
+#pragma unroll
+                for (int q = 0; q < HS_WGS; ++q) pv[q] = S.pd_in[q * NT + lane];
+            }
+        }
+    }
+    // ---- stage this workgroup's weight columns.  All pieces of the
     //      three slices (two per thread and slice, the second for the lower half of the threads) are requested before the
     //      first is stored: written as a copy loop per slice, each trip became load -> wait for everything outstanding (the
     //      A rows above included) -> store, six round trips one after the other.  A slice that is not live reads the first 16 bytes
@@ -365,23 +389,21 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
 #undef HB_ST
         if (lc) BsC[tid] = vc;
     }
-    if (tid < 3 * NT) {
-        const HbSlot& S = G.s[tid >> 5];
-        const int k = tid & 31;
-        float da = 0.f, al = 0.f; int v = 0;
-        if (S.present) {
-            v = S.valid[k]; al = S.alpha[k];
-            if (S.has_next) {
-#pragma unroll 8
-                for (int q = 0; q < HS_WGS; ++q) da += S.pd_in[q * NT + k];
-            }
+    if (rowdots) {
+        float da = 0.f;
+        asm volatile("" : "+v"(da));                         // (keeps the first addition, and its wait, behind the weight slices)
+        if (rd_next) {
+#pragma unroll
+            for (int q = 0; q < HS_WGS; ++q) da += pv[q];    // workgroup order, as the producing stage numbers them
         }
-        s_da[tid] = v ? da : 0.f; s_al[tid] = al; s_v[tid] = v;
+        s_da[wave * NT + lane] = rd_v ? da : 0.f; s_al[wave * NT + lane] = rd_al; s_v[wave * NT + lane] = rd_v;
     }
     __syncthreads();
 
     // ---- operands of the element-wise phase: requested now, consumed after the products
-    const int slot = tid < 512 ? tid >> 8 : 2;
+    // (a thread's slot is the same for its whole wave: as a scalar, the slot's descriptor is read with scalar loads from the
+    // kernel arguments; indexed per lane every field is a vector load and a round trip of its own in front of the operand)
+    const int slot = __builtin_amdgcn_readfirstlane(tid < 512 ? tid >> 8 : 2);
     const bool el = tid < 512 ? G.s[slot].present != 0 : (tid < 512 + NT && S2.present);
     const int H = slot == 2 ? 32 : 256;
     const int k = slot == 2 ? tid - 512 : (tid & 255) >> 3, jj = slot == 2 ? 0 : tid & 7, j = slot == 2 ? g : 8 * g + jj;
@@ -495,8 +517,8 @@ __global__ __launch_bounds__(1024) void k_head_stage_bwd(HbGroup G) {
     if (el && jj == 0 && G.s[slot].has_prev) G.s[slot].pd_out[g * NT + k] = pd;
     __syncthreads();
     // d(attention w) of this workgroup's columns: sum over the 32 tracks in track order
-    if (tid < 16) {
-        const int sl = tid >> 3, c = tid & 7;
+    if (wave < 2 && lane < 8) {                              // (one wave per slot, as above)
+        const int sl = wave, c = lane;
         if (G.s[sl].present) {
             float acc = 0.f;
 #pragma unroll
