@@ -471,3 +471,113 @@ extern "C" int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream)
     if (max_mn) hipLaunchKernelGGL(k_tile_reduce, dim3(evad_blocks(max_mn, 256), n_prob), dim3(256), 0, (hipStream_t)stream, g);
     return evad_last_error();
 }
+
+// =============================================================================================
+// Grouped GEMM on 64x64 tiles -- for the groups that are bound by MFMA throughput, not by latency.
+// On the head's 32 CUs the batched weight gradients (dW = dG^T . X over all clips: six products, up to 768 x 256 x R)
+// are 630 tiles of 32x32 in k_tile_gemm: every tile's operands are fetched by four waves that each hold a quarter of K,
+// staged with 4-byte LDS writes and summed across the waves through LDS.  Here a workgroup owns a 64x64 tile, each of
+// its 4 waves a 32x32 quadrant over the WHOLE K (a plain fmaf chain in k order: no cross-wave sum, no slabs, no second
+// launch whatever K is), the operands go through LDS once per workgroup -- half the loads per flop -- as 16-deep slabs,
+// double buffered, with the global loads of the next TWO slabs in flight (2 x 8 registers) while a slab multiplies.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_tile_gemm64(TGroup g) {
+    __shared__ float As[2][GBK][64 + 4];
+    __shared__ float Bs[2][GBK][64 + 4];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < TG_MAXP; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].block0) pi = i;
+    const TProb& P = g.p[pi];
+    const int local = blockIdx.x - P.block0;
+    const int m0 = (local / P.tiles_n) * 64, n0 = (local % P.tiles_n) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int M = P.M, N = P.N, K = P.K;
+    const bool ta = P.ta != 0, tb = P.tb != 0;
+    // k-major operand ([K, M] / [K, N]): thread -> k row tid / 16, 4 consecutive m / n; row-major ([M, K] / [N, K]): row tid / 4,
+    // 4 consecutive k
+    const int kr = tid >> 4, cq = (tid & 15) * 4, rw = tid >> 2, kq = (tid & 3) * 4;
+    const float* pa = ta ? P.A + (size_t)kr * P.lda + m0 + cq : P.A + (size_t)(m0 + rw) * P.lda + kq;
+    const float* pb = tb ? P.B + (size_t)(n0 + rw) * P.ldb + kq : P.B + (size_t)kr * P.ldb + n0 + cq;
+    const size_t sa = ta ? (size_t)GBK * P.lda : (size_t)GBK, sb = tb ? (size_t)GBK : (size_t)GBK * P.ldb;
+    auto fetch = [&](int k0, float4& va, float4& vb) {
+        va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va;
+        if (k0 >= K) return;
+        if (ta) { if (k0 + kr < K) va = ld4_guard(pa, m0 + cq, M); } else { if (m0 + rw < M) va = ld4_guard(pa, k0 + kq, K); }
+        if (tb) { if (n0 + rw < N) vb = ld4_guard(pb, k0 + kq, K); } else { if (k0 + kr < K) vb = ld4_guard(pb, n0 + cq, N); }
+        pa += sa; pb += sb;
+    };
+    auto stage = [&](int buf, const float4& va, const float4& vb) {
+        if (ta) *(float4*)&As[buf][kr][cq] = va;
+        else { As[buf][kq][rw] = va.x; As[buf][kq + 1][rw] = va.y; As[buf][kq + 2][rw] = va.z; As[buf][kq + 3][rw] = va.w; }
+        if (tb) { Bs[buf][kq][rw] = vb.x; Bs[buf][kq + 1][rw] = vb.y; Bs[buf][kq + 2][rw] = vb.z; Bs[buf][kq + 3][rw] = vb.w; }
+        else *(float4*)&Bs[buf][kr][cq] = vb;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int c = lane & 31, kh2 = lane >> 5;
+    auto slab = [&](int buf) {
+        float a[2], b[2];
+        a[0] = As[buf][kh2][wm + c]; b[0] = Bs[buf][kh2][wn + c];
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2) {
+            const int q = (kk >> 1) & 1;
+            if (kk + 2 < GBK) { a[q ^ 1] = As[buf][kk + 2 + kh2][wm + c]; b[q ^ 1] = Bs[buf][kk + 2 + kh2][wn + c]; }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+        }
+    };
+    // slab s multiplies out of LDS buffer s & 1 while the registers hold slabs s + 1 (va1/vb1) and s + 2 (va2/vb2)
+    float4 va0, vb0, va1, vb1, va2, vb2;
+    fetch(0, va0, vb0);
+    fetch(GBK, va1, vb1);
+    stage(0, va0, vb0);
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 2 * GBK) {
+        fetch(k0 + 2 * GBK, va2, vb2);
+        slab(0);
+        if (k0 + GBK < K) stage(1, va1, vb1);
+        __syncthreads();
+        if (k0 + GBK >= K) break;
+        fetch(k0 + 3 * GBK, va1, vb1);
+        slab(1);
+        if (k0 + 2 * GBK < K) stage(0, va2, vb2);
+        __syncthreads();
+    }
+    const int gn = n0 + wn + c;
+    if (gn >= N) return;
+    const float bias = P.bias ? P.bias[gn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+        if (gm >= M) continue;
+        float v = acc[r] + bias;
+        if (P.relu) v = fmaxf(v, 0.f);
+        if (P.acc) v += P.C[(size_t)gm * P.ldc + gn];
+        P.C[(size_t)gm * P.ldc + gn] = v;
+    }
+}
+
+/* Same descriptors as eventad_gemm_group ([2] and [15] are not used: there are no slabs). */
+extern "C" int eventad_gemm_group64(int n_prob, const int64_t* desc, void* stream) {
+    if (n_prob < 1 || n_prob > TG_MAXP || !desc) return EVAD_ERR_ARG;
+    TGroup g;
+    g.n = n_prob;
+    int blocks = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const int64_t* d = desc + 16 * i;
+        TProb& P = g.p[i];
+        P.A = (const float*)d[0]; P.B = (const float*)d[1]; P.part = nullptr; P.C = (float*)d[3]; P.bias = (const float*)d[4];
+        P.lda = (int)d[5]; P.ldb = (int)d[6]; P.ldc = (int)d[7]; P.M = (int)d[8]; P.N = (int)d[9]; P.K = (int)d[10];
+        P.ta = (int)d[11]; P.tb = (int)d[12]; P.acc = (int)d[13]; P.relu = (int)d[14];
+        P.keep_slabs = 0; P.cnt = nullptr;
+        if (!P.A || !P.B || !P.C || P.M < 1 || P.N < 1 || P.K < 1 || (P.lda & 3) || (P.ldb & 3) || !al16(P.A) || !al16(P.B) ||
+            P.ldc < P.N || P.lda < (P.ta ? P.M : P.K) || P.ldb < (P.tb ? P.K : P.N))
+            return EVAD_ERR_ARG;
+        P.tiles_m = (P.M + 63) / 64; P.tiles_n = (P.N + 63) / 64; P.ksplit = 1; P.kgroups = 1; P.block0 = blocks;
+        blocks += P.tiles_m * P.tiles_n;
+    }
+    hipLaunchKernelGGL(k_tile_gemm64, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return evad_last_error();
+}

@@ -25,6 +25,12 @@ _TILE_CNT = os.environ.get("EVENTAD_TILE_CNT", "0") == "1"
 # Measured on C2 (same box, A/B): head graph 0.695 ms with, 0.630 ms without -- the extra loads sit on the one-workgroup
 # critical path and cost more than the 5 us launch they save.  Off.
 _KEEP_SLABS = os.environ.get("EVENTAD_KEEP_SLABS", "0") == "1"
+# Which of the head's six batched GEMM launches run on 64x64 tiles over the whole K (eventad_gemm_group64) instead of 32x32
+# tiles with K split over the waves; bit i = launch i in program order.  C2, same box, head on its 32 CUs: the input
+# projections (bit 0: K = 64 leaves three of the four waves of a 32x32 tile idle) 20 -> 10 us, the recurrent layers' weight
+# gradients over all clips (bit 5: 630 small tiles) 50 -> 36 us; the fusion layers (bits 1-4: few tiles, long K) are latency
+# bound and lose or stay (step 0.576 -> 0.559 ms with 33, 0.571 with all six).
+_WIDE = int(os.environ.get("EVENTAD_GG64", "33"))
 # forward recurrence: one fused launch per clip stage (attention of the previous clip + recurrent products + cell,
 # csrc/headstage.hip) instead of a grouped GEMM and a cell+attention launch.  0 = the two-launch form (kept for A/B runs).
 _STAGE_FWD = os.environ.get("EVENTAD_HEAD_STAGE", "1") == "1"
@@ -119,8 +125,8 @@ class NativeHead:
         self._B = B
 
     # ------------------------------------------------------------ launch helpers
-    def _gg(self, *probs):
-        """One grouped-GEMM launch.  prob = (ta, tb, A, lda, B, ldb, C, ldc, M, N, K[, bias[, relu[, acc[, keep]]]]);
+    def _gg(self, *probs, wide=False):
+        """One grouped-GEMM launch (wide: on 64x64 tiles over the whole K instead of 32x32 tiles with K split over the waves).  prob = (ta, tb, A, lda, B, ldb, C, ldc, M, N, K[, bias[, relu[, acc[, keep]]]]);
         keep = leave the split-K slabs of a K > 256 product un-summed in self.w["part"][i] for the consumer."""
         d = (ctypes.c_int64 * (16 * len(probs)))()
         for i, pr in enumerate(probs):
@@ -136,7 +142,8 @@ class NativeHead:
             d[16 * i:16 * i + 16] = [A.data_ptr(), Bm.data_ptr(), self.w["part"][i].data_ptr() if K > 256 else 0, C.data_ptr(),
                                      bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu,
                                      1 if (keep and K > 256) else (self.w["cnt"][i].data_ptr() if (K > 256 and _TILE_CNT) else 0)]
-        call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
+        call("eventad_gemm_group64" if wide else "eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p),
+             torch.cuda.current_stream().cuda_stream)
 
     @staticmethod
     def _desc(fn, width, rows, *extra):
@@ -214,7 +221,7 @@ class NativeHead:
         fused_fwd = self.stage_fwd
         self._fw_fused = fused_fwd
         if fused_fwd:
-            self._gg(*input_proj)
+            self._gg(*input_proj, wide=_WIDE & 1)
             self._forward_chain_fused(B, train)
         for b in range(0 if fused_fwd else B + 1):
             gemms, steps = (list(input_proj) if b == 0 else []), []
@@ -237,8 +244,9 @@ class NativeHead:
             self._desc("eventad_gru_att_fwd_group", 12, steps)
         # fusion MLP on all rows at once (Fuse_GRUNet.forward, EventAD.py:30-59)
         self._gg((0, 1, w["H1n"], 256, P[fu + "event_proj.weight"], 256, w["ZCAT"], 512, R, 256, 256, P[fu + "event_proj.bias"]),
-                 (0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, P[fu + "coord_proj.bias"]))
-        self._gg((0, 1, w["ZCAT"], 512, P[fu + "fusion.0.weight"], 512, w["F1r"], 256, R, 256, 512, P[fu + "fusion.0.bias"], 1))
+                 (0, 1, w["HCn"], 32, P[fu + "coord_proj.weight"], 32, w["ZCAT"][:, 256:], 512, R, 256, 32, P[fu + "coord_proj.bias"]),
+                 wide=_WIDE & 2)
+        self._gg((0, 1, w["ZCAT"], 512, P[fu + "fusion.0.weight"], 512, w["F1r"], 256, R, 256, 512, P[fu + "fusion.0.bias"], 1), wide=_WIDE & 4)
         # a training loop (lean) reads the loss after the step: its rows are then added by the first launch of backward()
         # instead of a launch of their own here
         self._loss_deferred = bool(lean and train)
@@ -302,11 +310,11 @@ class NativeHead:
         self._loss_deferred = False
         dE, dC = w["dZCAT"], w["dZCAT"][:, 256:]
         self._gg((1, 0, w["dPre"], 256, w["ZCAT"], 512, G[fu + "fusion.0.weight"], 512, 256, 512, R),
-                 (0, 0, w["dPre"], 256, P[fu + "fusion.0.weight"], 512, w["dZCAT"], 512, R, 512, 256))
+                 (0, 0, w["dPre"], 256, P[fu + "fusion.0.weight"], 512, w["dZCAT"], 512, R, 512, 256), wide=_WIDE & 8)
         self._gg((1, 0, dE, 512, w["H1n"], 256, G[fu + "event_proj.weight"], 256, 256, 256, R),
                  (0, 0, dE, 512, P[fu + "event_proj.weight"], 256, w["dH1o"], 256, R, 256, 256),
                  (1, 0, dC, 512, w["HCn"], 32, G[fu + "coord_proj.weight"], 32, 256, 32, R),
-                 (0, 0, dC, 512, P[fu + "coord_proj.weight"], 32, w["dHCo"], 32, R, 32, 256))
+                 (0, 0, dC, 512, P[fu + "coord_proj.weight"], 32, w["dHCo"], 32, R, 32, 256), wide=_WIDE & 16)
         # (the bias gradients of these three layers are column sums of dPre / dZCAT, which stay as they are until the end
         # of backward(): they ride in its last column-sum launch)
         # dS of the state after the last clip is zero: a constant zero buffer read by the first stage of each chain
@@ -374,7 +382,7 @@ class NativeHead:
                  (1, 0, w["dGI1"], 768, w["X1"], 256, G[ev + "weight_ih_l1"], 256, 768, 256, R),
                  (1, 0, w["dGH1"], 768, w["S1"], 256, G[ev + "weight_hh_l1"], 256, 768, 256, R),
                  (1, 0, w["dGIC"], 96, w["CO"], 4, G[co + "weight_ih_l0"], 4, 96, 4, R),
-                 (1, 0, w["dGHC"], 96, w["SC"], 32, G[co + "weight_hh_l0"], 32, 96, 32, R))
+                 (1, 0, w["dGHC"], 96, w["SC"], 32, G[co + "weight_hh_l0"], 32, 96, 32, R), wide=_WIDE & 32)
         # every bias gradient of the head (a column sum over the R rows) in one launch, together with the attention vectors:
         # [dwatt0 | dwattc] + [dwatt1 | 0] is the column sum of the accumulator seen as a 2-row matrix
         self._desc("eventad_colsum_group", 5,

@@ -307,6 +307,11 @@ int eventad_head_stage_bwd(const int64_t* desc, void* stream);
  * by the last workgroup to reach the tile instead of by a second launch; the value 1 = leave the slabs of a K > 256
  * product un-summed in `part` for a consumer that adds them itself (eventad_gru_att_bwd_group does). */
 int eventad_gemm_group(int n_prob, const int64_t* desc, void* stream);
+/* The same products on 64x64 tiles: a workgroup's 4 waves own the quadrants of its tile over the whole K (one fmaf chain in
+ * k order per output: no K split, no slabs, no second launch), operands staged through LDS once per workgroup.  For groups
+ * that are bound by MFMA throughput rather than latency -- the head's batched weight gradients dW = dG^T . X over all clips
+ * (what autograd does for nn.GRU / nn.Linear weights of models/EventAD.py:16-97).  Same descriptors; [2] and [15] are ignored. */
+int eventad_gemm_group64(int n_prob, const int64_t* desc, void* stream);
 /* fusion[3] Linear(256,2) + summed cross-entropy (EventAD.py:27,280-281) and its backward.  eventad_fuse_out with dPre
  * non-NULL also writes dPre f32[R,256] = d loss / d (pre-activation of the hidden layer), which eventad_out_bwd then need
  * not compute (pass its dPre = NULL); eventad_out_bwd also clears the n_clear floats at `clear` (nullable): accumulators

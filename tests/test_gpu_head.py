@@ -126,7 +126,8 @@ def test_gemm_variants():
         assert torch.allclose(C, ref, atol=2e-4, rtol=1e-4), (ta, tb, M, N, K, float((C - ref).abs().max()))
 
 
-def test_grouped_tile_gemm():
+@pytest.mark.parametrize("entry", ["eventad_gemm_group", "eventad_gemm_group64"])
+def test_grouped_tile_gemm(entry):
     import ctypes
     from eventad_amd._lib import call
     g = torch.Generator().manual_seed(2)
@@ -145,7 +146,7 @@ def test_grouped_tile_gemm():
     d = (ctypes.c_int64 * (16 * len(probs)))()
     for i, pr in enumerate(probs):
         d[16 * i:16 * i + 15] = [v.data_ptr() if isinstance(v, torch.Tensor) else v for v in pr]
-    call("eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
+    call(entry, len(probs), ctypes.cast(d, ctypes.c_void_p), torch.cuda.current_stream().cuda_stream)
     for pr, ref, shp in zip(probs, refs, shapes):
         assert torch.allclose(pr[3], ref, atol=2e-4, rtol=1e-4), (shp, float((pr[3] - ref).abs().max()))
 
