@@ -1131,6 +1131,98 @@ __device__ __forceinline__ void ell_pix_pass(const int2* __restrict__ ev2, const
     PIX_LDS_ORDER();
 }
 
+// First pass for DEEP pixels (tens of events per pixel: the 32 M-event configuration).  With the newest DEPTH entries of a
+// neighbour pixel in registers, an event in the middle of the clip finds all of them newer than itself and reads on from
+// memory, four entries per dependent round trip, past every newer entry and then through its sources -- 6 to 10 round trips
+// per event, which is where such a pixel's time went.  But a group's events come in ascending id, ids and timestamps ascend
+// inside a segment, and both "older than the event" and "inside its time window" are prefixes / suffixes of the segment that
+// only move UP from one event to the next.  So a lane keeps two positions in its neighbour's segment across the events of
+// the pixel: p = newest entry older than the event, q = oldest entry inside the event's time window.  The sources are the
+// entries q..p, newest first -- counted by subtraction, not by walking -- and per event each position advances by about one
+// entry (DEEP_WIN entries are looked at per round trip).  The first event of a group in a pixel finds both positions by
+// binary search.  Same rows as ell_pix_pass: the sums over the lower lanes, the 16-slot cut and the slot order are its code.
+#define DEEP_WIN 4
+template <int GS, bool INT_CMP>
+__device__ __forceinline__ void ell_pix_pass_deep(const int2* __restrict__ ev2, int N, int Q, int dt_max, int* my_src,
+                                                  unsigned short* my_stp, const int2* my_dest, int* my_cnt, int st, int en,
+                                                  int& p, int& q, bool& fresh) {
+    constexpr int MAXNB = 16, NG = 64 / GS;
+    struct __attribute__((aligned(8))) Piece { int4 v; };
+    const int lane = threadIdx.x & 63, g = lane / GS, l = lane % GS;
+    const float fdt = (float)dt_max;
+    const int lo = max(st, en - Q);                          // the FIFO keeps only the newest Q ids
+    unsigned long long todo = __ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB);
+    while (todo) {
+        int d = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+#pragma unroll
+        for (int k = 1; k < NG; ++k) {
+            const int dk = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            d = g == k ? dk : d;
+        }
+        const bool act = d >= 0;
+        d = max(d, 0);
+        const int base = my_cnt[d];
+        const int2 mine = my_dest[d];
+        const int me = mine.x, ts = mine.y, t_min = ts - dt_max;
+        bool more = act;
+        if (__any(fresh && act)) {
+            // a = first entry that is not older than the event, a2 = first entry inside its time window
+            const bool go = fresh && act;
+            int a = go ? lo : 0, b = go ? en : 0, a2 = a, b2 = b;
+            while (__any(a < b || a2 < b2)) {
+                if (a < b) { const int m = (a + b) >> 1; if (ev2[m].x < me) a = m + 1; else b = m; }
+                if (a2 < b2) {
+                    const int m = (a2 + b2) >> 1, t = ev2[m].y;
+                    if (INT_CMP ? t < t_min : (float)(ts - t) > fdt) a2 = m + 1; else b2 = m;
+                }
+            }
+            if (go) { p = a - 1; q = a2; fresh = false; more = false; }
+        }
+        while (__any(more)) {                                // both positions move up past the entries this event leaves behind
+            if (more) {
+                bool okp = true, okq = true;
+                int advp = 0, advq = 0;
+                int4 rp[DEEP_WIN / 2], rq[DEEP_WIN / 2];
+#pragma unroll
+                for (int k = 0; k < DEEP_WIN / 2; ++k) {     // 16-byte loads of two entries each, every address inside the array
+                    rp[k] = ((const Piece*)(ev2 + min(p + 1 + 2 * k, N - 2)))->v;
+                    rq[k] = ((const Piece*)(ev2 + min(q + 2 * k, N - 2)))->v;
+                }
+#pragma unroll
+                for (int k = 0; k < DEEP_WIN / 2; ++k) {
+                    const int ip = p + 1 + 2 * k, iq = q + 2 * k;
+                    const int id0 = ip > N - 2 ? rp[k].z : rp[k].x, id1 = rp[k].z;       // entries ip and ip + 1
+                    const int t0 = iq > N - 2 ? rq[k].w : rq[k].y, t1 = rq[k].w;          // entries iq and iq + 1
+                    okp = okp && ip < en && id0 < me;          advp += okp ? 1 : 0;
+                    okp = okp && ip + 1 < en && id1 < me;      advp += okp ? 1 : 0;
+                    okq = okq && iq < en && (INT_CMP ? t0 < t_min : (float)(ts - t0) > fdt);       advq += okq ? 1 : 0;
+                    okq = okq && iq + 1 < en && (INT_CMP ? t1 < t_min : (float)(ts - t1) > fdt);   advq += okq ? 1 : 0;
+                }
+                p += advp; q += advq;
+                more = okp || okq;                           // every entry looked at was left behind: look further
+            }
+        }
+        const int nq = act ? min(MAXNB, max(0, p - q + 1)) : 0;
+        int inc = nq;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+        if (GS >= 32) inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);    // row_bcast15 -> rows 1 and 3
+        if (GS == 64) inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);    // row_bcast31 -> rows 2 and 3
+        const int off = inc - nq;
+        const int take = min(nq, MAXNB - base - off);        // slots left for this lane's sources
+        for (int k = 0; k < take; ++k) {
+            my_src[d * MAXNB + base + off + k] = p - k;
+            my_stp[d * MAXNB + base + off + k] = (unsigned short)l;
+        }
+        if (l == GS - 1 && act) my_cnt[d] = min(MAXNB, base + inc);      // the group's last lane holds the total
+    }
+    PIX_LDS_ORDER();
+}
+
 // Batches whose timestamps are not monotone in the id (rare): plain per-event walk over the events [ds, de) of the pixel
 // (x, y), one event per lane, rows written slot by slot; the reference's `continue` on a too-old entry matters here.
 __device__ __forceinline__ void pix_walk_events(const int2* __restrict__ ev2, const unsigned* __restrict__ start, int ds, int de, int x,
@@ -1169,7 +1261,7 @@ __device__ __forceinline__ void pix_walk_events(const int2* __restrict__ ev2, co
 // wave per workgroup, dealt pixel by pixel over all CUs, missed it on nearly every line and waited for L2).  Strips are
 // numbered so that each XCD (workgroup id mod 8) owns one contiguous eighth of them: its L2 then holds one band of rows.
 #define PIX_STRIP 16
-template <int GS1, bool INT_CMP, int DEPTH>
+template <int GS1, bool INT_CMP, int DEPTH, bool DEEP = false>
 __global__ __launch_bounds__(256, DEPTH <= 2 ? 8 : 5) void k_build_ell_pix(const int2* __restrict__ ev2, const unsigned* __restrict__ start,
                                                       const unsigned* __restrict__ flags_in, int N, int n_strips, int W, int H, int steps,
                                                       int sp0, int Q, int dt_max, int* __restrict__ ell_src,
@@ -1208,6 +1300,10 @@ __global__ __launch_bounds__(256, DEPTH <= 2 ? 8 : 5) void k_build_ell_pix(const
         }
         if (de <= ds) continue;
         if (walk) { pix_walk_events(ev2, start, ds, de, x, y, plane_base, W, H, steps, sp0, Q, dt_max, ell_src, ell_step, deg); continue; }
+        // (DEEP) positions in the first pass's neighbour segments, kept from event to event of the pixel
+        const int lo1 = max(st1, en1 - Q);
+        int dp_p = lo1 - 1, dp_q = lo1;
+        bool dp_fresh = true;
         for (int d0 = ds; d0 < de; d0 += PIX_CHUNK) {        // the pixel's destination events, PIX_CHUNK at a time
             const int md = min(PIX_CHUNK, de - d0);
             if (lane < PIX_CHUNK) {
@@ -1219,7 +1315,8 @@ __global__ __launch_bounds__(256, DEPTH <= 2 ? 8 : 5) void k_build_ell_pix(const
             PIX_LDS_ORDER();
             if (lane < PIX_CHUNK) my_src[lane * MAXNB] = d0 + lane;
             PIX_LDS_ORDER();
-            ell_pix_pass<GS1, INT_CMP, true, DEPTH>(ev2, start, N, W, H, first, sp0, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt, st1, en1);
+            if (DEEP) ell_pix_pass_deep<GS1, INT_CMP>(ev2, N, Q, dt_max, my_src, my_stp, my_dest, my_cnt, st1, en1, dp_p, dp_q, dp_fresh);
+            else ell_pix_pass<GS1, INT_CMP, true, DEPTH>(ev2, start, N, W, H, first, sp0, Q, dt_max, x, y, plane_base, 0, md, my_src, my_stp, my_dest, my_cnt, st1, en1);
             for (int i0 = first; i0 < steps; i0 += 64) {
                 if (!__ballot(lane < PIX_CHUNK && my_cnt[lane & (PIX_CHUNK - 1)] < MAXNB)) break;
                 ell_pix_pass<64, INT_CMP, false, DEPTH>(ev2, start, N, W, H, steps, sp0, Q, dt_max, x, y, plane_base, i0, md, my_src, my_stp, my_dest, my_cnt, 0, 0);
@@ -1502,7 +1599,7 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         if (radius_px == 1) { if (bitmap) EVAD_RS(1, true); else EVAD_RS(1, false); }
         else                { if (bitmap) EVAD_RS(3, true); else EVAD_RS(3, false); }
 #undef EVAD_RS
-    } else if (fast && !bitmap && (variant == 2 || variant == 4 || (variant == 0 && (double)N >= 0.4 * (double)B * W * H))) {
+    } else if (fast && !bitmap && (variant == 2 || variant == 4 || variant == 5 || variant == 6 || (variant == 0 && (double)N >= 0.4 * (double)B * W * H))) {
         // (measured crossover against the per-event walk: 0.3-0.4 events per pixel at radius 13, below 1.4 at radius 3)
         const long long P = (long long)B * W * H;            // wave per pixel
         const long long strips = (long long)B * H * ((W + PIX_STRIP - 1) / PIX_STRIP);
@@ -1517,7 +1614,18 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
         // large windows at low density (or asked for: variant 4): ring bands in row-major lane order, non-empty pixels only
         // (measured equal to the spiral-order form at 1280x720 / 0.54 events per pixel -- 4.99 against 4.96 ms -- and slower at
         // 640x480 / 0.98: both forms are bound by instruction issue, ~600-900 per pixel, not by loads: on request only)
-        if (sp->passes.n > 0 && variant == 4) {
+        // deep pixels (from 20 events per pixel, or asked for: variant 5): the first pass keeps two positions per neighbour
+        // segment instead of the newest entries (ell_pix_pass_deep).  256x256, radius 3, 8 M events at 30 per pixel: 2.54 ms
+        // against 3.03 for the register form with the same 16-step first pass; 0.69 against 0.57 at 9 per pixel; 640x480,
+        // radius 7, 13 per pixel: 2.50 against 2.06
+        const bool deep = N >= 2 && (variant == 5 || (variant == 0 && (double)N >= 20.0 * (double)P));
+        if (deep) {
+            if (int_cmp) hipLaunchKernelGGL((k_build_ell_pix<16, true, 8, true>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start,
+                                            counters, N, n_strips, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg);
+            else         hipLaunchKernelGGL((k_build_ell_pix<16, false, 8, true>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start,
+                                            counters, N, n_strips, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg);
+        }
+        else if (sp->passes.n > 0 && variant == 4) {
             if (int_cmp) hipLaunchKernelGGL((k_build_ell_pixr<true>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, counters,
                                             sp->band, sp->passes, N, n_strips, W, H, queue_size, delta_t_us, ell_src, ell_step, deg);
             else         hipLaunchKernelGGL((k_build_ell_pixr<false>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start, counters,
@@ -1536,6 +1644,10 @@ extern "C" int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const 
             hipLaunchKernelGGL((k_build_ell_pix<64, true, 2>), dim3((unsigned)wgs), dim3(256), 0, st, (const int2*)ev2, pix_start,
                                counters, N, n_strips, W, H, steps, sp0, queue_size, delta_t_us, ell_src, ell_step, deg);
         }
+        // from five events per pixel: four events at a time on 16 steps each, whatever the radius (the whole 49-step spiral
+        // of radius 3 in one pass, one event at a time, is 0.41 against 0.56 ms at 3 events per pixel -- but 0.99 against 0.57
+        // at 9 and 9.25 against 3.03 at 30); variant 6 asks for this form
+        else if (variant == 6 || (variant == 0 && very_dense)) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
         else if (steps <= 64 || (double)N < 2.0 * (double)P) { if (int_cmp) EVAD_PIX(64, true); else EVAD_PIX(64, false); }      // (... or few events per pixel)
         else if (very_dense) { if (int_cmp) EVAD_PIX(16, true); else EVAD_PIX(16, false); }
         else                 { if (int_cmp) EVAD_PIX(32, true); else EVAD_PIX(32, false); }

@@ -460,6 +460,15 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __r
                                                float lr, float beta1, float omb1, float beta2, float omb2, float eps, float decay,
                                                float max_norm, const float* __restrict__ partial, float* __restrict__ state) {
     __shared__ float s_norm;
+    // A thread's elements (two groups of four consecutive ones, a grid apart: 16-byte loads and stores; the update is pure
+    // streaming, 7 floats of traffic per parameter, and runs on the head's CU share) are requested BEFORE the norm is formed
+    // from the partial sums, so that round trip and the barrier hide under the loads.
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+    const int i0 = 4 * tid, i1 = 4 * (tid + nthr);
+    const bool full0 = i0 + 3 < n, full1 = i1 + 3 < n;
+    float4 p4[2], g4[2], m4[2], v4[2];
+    if (full0) { p4[0] = *(const float4*)(p + i0); g4[0] = *(const float4*)(g + i0); m4[0] = *(const float4*)(m + i0); v4[0] = *(const float4*)(v + i0); }
+    if (full1) { p4[1] = *(const float4*)(p + i1); g4[1] = *(const float4*)(g + i1); m4[1] = *(const float4*)(m + i1); v4[1] = *(const float4*)(v + i1); }
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         float s = (partial[lane] + partial[64 + lane]) + (partial[128 + lane] + partial[192 + lane]);
@@ -490,15 +499,16 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __r
         const float denom = sqrtf(vi) / bc2s + eps;
         pw = pi - (lr / bc1) * (mi / denom);
     };
-    // four consecutive elements per thread (16-byte loads and stores: the update is pure streaming, 7 floats of traffic per
-    // parameter, and runs on the head's CU share)
-    const int i = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (i + 3 < n) {
-        float4 p4 = *(float4*)(p + i), g4 = *(float4*)(g + i), m4 = *(float4*)(m + i), v4 = *(float4*)(v + i);
-        one(p4.x, g4.x, m4.x, v4.x); one(p4.y, g4.y, m4.y, v4.y); one(p4.z, g4.z, m4.z, v4.z); one(p4.w, g4.w, m4.w, v4.w);
-        *(float4*)(g + i) = g4; *(float4*)(m + i) = m4; *(float4*)(v + i) = v4; *(float4*)(p + i) = p4;
-    } else {
-        for (int k = i; k < n; ++k) one(p[k], g[k], m[k], v[k]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = h ? i1 : i0;
+        if (h ? full1 : full0) {
+            one(p4[h].x, g4[h].x, m4[h].x, v4[h].x); one(p4[h].y, g4[h].y, m4[h].y, v4[h].y);
+            one(p4[h].z, g4[h].z, m4[h].z, v4[h].z); one(p4[h].w, g4[h].w, m4[h].w, v4[h].w);
+            *(float4*)(g + i) = g4[h]; *(float4*)(m + i) = m4[h]; *(float4*)(v + i) = v4[h]; *(float4*)(p + i) = p4[h];
+        } else {
+            for (int k = i; k < min(i + 4, n); ++k) one(p[k], g[k], m[k], v[k]);      // (the last, partial group of four)
+        }
     }
 }
 
@@ -509,7 +519,7 @@ extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, f
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sqnorm_partial, dim3(NORM_BLOCKS), dim3(256), 0, st, grads, n, partial, beta1, beta2, state);
-    hipLaunchKernelGGL(k_adamw, dim3(evad_blocks(((long long)n + 3) / 4, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (float)lr,
+    hipLaunchKernelGGL(k_adamw, dim3(evad_blocks(((long long)n + 7) / 8, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (float)lr,
                        (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                        (float)(1.0 - lr * weight_decay), (float)max_norm, partial, state);
     return evad_last_error();

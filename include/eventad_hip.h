@@ -117,7 +117,11 @@ int eventad_sort_events_static(const float* pos, const int64_t* batch, const flo
  * density (bitmap must be NULL, else as 3); 3 = thread per event whatever the density; 4 = the wave-per-pixel search in its
  * ring-band form (lanes take the pixels of a band of whole rings in row-major order, so bounds and entries are coalesced
  * loads, and source counts are put into spiral order through an LDS table; non-empty pixels only; bitmap must be NULL; not
- * picked by 0: it measures equal to 2 at 1280x720 and slower at 640x480).  Identical rows in every case.
+ * picked by 0: it measures equal to 2 at 1280x720 and slower at 640x480); 5 = wave per pixel with the first pass in its
+ * deep-pixel form (a lane keeps two positions in its neighbour's segment -- newest entry older than the event, oldest entry
+ * inside its time window -- that move up from event to event of the pixel, instead of the newest entries in registers;
+ * bitmap must be NULL; picked by 0 from 20 events per pixel on average); 6 = wave per pixel with a first pass of four events
+ * at a time on 16 spiral steps each, entries in registers (picked by 0 from 5 events per pixel).  Identical rows in every case.
  * bitmap_prezeroed != 0: the caller already cleared the bitmap. */
 int eventad_build_ell(const int32_t* sid, const int32_t* ts_s, const int32_t* ev2, const int32_t* key_s,
                       const uint32_t* pix_start, uint32_t* counters, int N, int B, int W, int H, int radius_px, int delta_t_us,

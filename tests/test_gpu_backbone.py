@@ -206,7 +206,7 @@ def test_wave_per_pixel_edge_search_equals_the_walk_on_dense_input():
     dev = torch.device("cuda:0")
     nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
     outs = []
-    for variant in (3, None, 2, 4):
+    for variant in (3, None, 2, 4, 5, 6):
         nb.ell_variant = variant
         outs.append(_ell_rows(nb, data, B, dev))
     assert int((outs[0][0] < 16).sum()) > 1000 and float((outs[0][0] == 16).float().mean()) > 0.5
@@ -214,6 +214,35 @@ def test_wave_per_pixel_edge_search_equals_the_walk_on_dense_input():
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+def test_deep_pixel_edge_search_equals_the_walk():
+    """Tens of events per pixel (the 32 M-event configuration's density, here 64x64 x 2 clips): 24 events per pixel on
+    average, one pixel with 300 events (more than the FIFO keeps), a time window shorter than the clip so that the window's
+    lower end moves through the segments too, and a window beyond float precision.  The deep-pixel first pass (what this
+    density gets by default, and forced as variant 5) gives the rows of the per-event walk."""
+    from oracle import dagr_ref
+    from eventad_amd.backbone import NativeBackbone
+    W = H = 64
+    B = 2
+    raw = synthetic.make_batch(W, H, 100000, B, with_image=False, precomputed_feats=True)
+    raw.pos[5000:5300] = torch.tensor([10, 20], dtype=raw.pos.dtype)
+    data = dagr_ref.format_data(raw)
+    dev = torch.device("cuda:0")
+    nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
+    for delta_t in (nb.geom.delta_t_us, 3000, (1 << 24) + 5):
+        nb.geom.delta_t_us = delta_t
+        outs = []
+        for variant in (3, None, 5, 2, 6):
+            nb.ell_variant = variant
+            outs.append(_ell_rows(nb, data, B, dev))
+        if delta_t == 3000:
+            assert int((outs[0][0] < 16).sum()) > 1000           # the short window leaves rows unfilled
+        else:
+            assert float((outs[0][0] == 16).float().mean()) > 0.5
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert torch.equal(a, b)
 
 
 def test_wave_per_pixel_edge_search_with_a_time_window_beyond_float_precision():
@@ -227,7 +256,7 @@ def test_wave_per_pixel_edge_search_with_a_time_window_beyond_float_precision():
     nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
     nb.geom.delta_t_us = (1 << 24) + 5
     outs = []
-    for variant in (3, 2, 4):
+    for variant in (3, 2, 4, 5):
         nb.ell_variant = variant
         outs.append(_ell_rows(nb, data, 2, dev))
     assert float((outs[0][0] == 16).float().mean()) > 0.5
@@ -246,7 +275,7 @@ def test_both_edge_search_kernels_give_the_same_rows():
     data = dagr_ref.format_data(data)
     dev = torch.device("cuda:0")
     outs = []
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5, 6):
         nb = NativeBackbone(weights.random_graph_state(), W, H, dev)
         nb.ell_variant = variant
         res = nb.forward(data.pos.to(dev), data.x.to(dev), data.batch.to(dev), 3, [m.to(dev) for m in data.image_feats])
