@@ -47,8 +47,9 @@ def _clips(W, H, ns, **kw):
 
 
 # ell_variant: None = the edge search the density heuristic picks, 2 = the wave-per-pixel search forced, 4 = its ring-band
-# form forced (row-major lane order, non-empty pixels only; non-monotone batches: the exact walk launched behind it)
-VARIANTS = [None, 2, 4]
+# form forced (row-major lane order, non-empty pixels only; non-monotone batches: the exact walk launched behind it),
+# 5 = its deep-pixel first pass forced (two positions per neighbour segment), 6 = its 16-step first pass forced
+VARIANTS = [None, 2, 4, 5, 6]
 
 
 @pytest.mark.parametrize("ell_variant", VARIANTS)
