@@ -104,9 +104,10 @@ def test_single_event_batch():
     _run(EventBatch.from_clips(_clips(W, H, [1])), W, H, 1)
 
 
-@pytest.mark.parametrize("cfg", ["C2", "C3", "C5"])
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_full_size_properties(cfg):
-    """At the full sizes of the benchmark configurations (C2: 400k events; C3: 6.4M events, spiral-walk edge search; C5: 32M events at 640x480,
+    """At the full sizes of the benchmark configurations (C2: 400k events; C3: 6.4M events, spiral-walk edge search; C4: one GPU's 8 clips x 500k
+    events at 1280x720, search radius 13, two-entry wave-per-pixel search and the tail-ranked convolutions; C5: 32M events at 640x480,
     search radius 7, rank-dealt spiral walk and the partly-in-LDS LUT) the oracle is too slow for the CI budget: check
     invariants of the graph and of every pooled level instead."""
     from eventad_amd.backbone import NativeBackbone
