@@ -82,9 +82,10 @@ def _ev_graph_module():
     return m
 
 
-# the test/validation loop: only these two modules of the reference's `utils` package are replaced --
+# the test/validation loop: only these modules of the reference's `utils` package are replaced (test, evaluation, fps) --
 # the package itself (data loaders, result files, ...) stays the reference's, so they are registered as submodules
-_EVAL_ALIASES = {"utils.test": "eventad_amd.utils.test", "utils.evaluation": "eventad_amd.utils.evaluation"}
+_EVAL_ALIASES = {"utils.test": "eventad_amd.utils.test", "utils.evaluation": "eventad_amd.utils.evaluation",
+                 "utils.fps": "eventad_amd.utils.fps"}
 
 
 def install(eval_loop=False):

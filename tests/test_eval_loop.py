@@ -90,3 +90,37 @@ def test_collect_predictions_on_the_hip_model_equals_its_nested_list_output():
     slow = _quiet(collect_predictions, Nested(model), mk(), torch.device("cuda"), None, 0.5)
     assert len(fast["all_scores"]) > 0
     _close(clean(fast), clean(slow), tol=0.0)
+
+
+def test_measure_fps_counts_boxes_of_both_frames_and_skips_empty_batches():
+    """measure_fps keeps the reference's bookkeeping (utils/fps.py:37-86): the loader index counts warm-up batches, batches
+    without boxes are skipped, the unit is len(bbox) + len(bbox0), the model is called as model(data, labels, testing=True)
+    in evaluation mode."""
+    from types import SimpleNamespace
+    import torch
+    from eventad_amd.utils.fps import measure_fps
+
+    class Batch(SimpleNamespace):
+        def to(self, device):
+            return self
+
+    def batch(m, m0):
+        return Batch(bbox=torch.zeros(m, 6), bbox0=torch.zeros(m0, 6), num_graphs=2, pos=torch.zeros(4, 2, dtype=torch.int16),
+                     t=torch.zeros(4, dtype=torch.int32), x=torch.zeros(4, 1, dtype=torch.int8), batch=torch.zeros(4, dtype=torch.long),
+                     width=torch.tensor([8, 8]), height=torch.tensor([8, 8]), time_window=torch.tensor([1000, 1000]), image=None)
+
+    calls = []
+
+    class Model(torch.nn.Module):
+        def forward(self, data, labels, testing=False):
+            calls.append((int(data.bbox.shape[0]), int(labels.shape[0]), testing, self.training))
+            return None
+
+    loader = [batch(3, 2), batch(0, 0), batch(4, 4), batch(5, 1), batch(0, 3), batch(2, 2), batch(7, 7)]
+    res = measure_fps(Model().train(), loader, torch.device("cpu"), warmup_batches=2, num_batches=3)
+    # index 0 is warm-up, index 1 is skipped (still inside the warm-up range), 2, 3 and 5 are timed, 4 has no boxes, 6 is beyond num_batches
+    assert [c[0] for c in calls] == [3, 4, 5, 2]
+    assert all(c[2] is True and c[3] is False and c[0] == c[1] for c in calls)
+    assert res["batches"] == 3 and res["avg_batch_size"] == (8 + 6 + 4) / 3
+    assert res["total_time"] > 0 and abs(res["fps"] - 18 / res["total_time"]) < 1e-9
+    assert set(res) >= {"fps", "avg_batch_size", "total_time"}
