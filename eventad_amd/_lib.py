@@ -65,3 +65,12 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "native kernels need contiguous tensors"
     return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    """Raw handle of torch's current stream on the current device -- the value of torch.cuda.current_stream().cuda_stream
+    without building the Stream object (about 7 us per call: a tenth of the host time of an eager forward pass of a few
+    hundred launches)."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib, spline
-from ._lib import call, ptr
+from ._lib import call, ptr, stream_handle
 from .geometry import Geometry
 from .weights import LAYER_NAMES, LAYER_DIMS
 
@@ -18,7 +18,7 @@ FEATURE_CHANNELS = [16, 64, 64, 64, 64]
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return stream_handle()
 
 
 def _rp(t):

@@ -44,8 +44,15 @@ class DAGR(nn.Module):
     def forward(self, x, reset=True, return_targets=True, filtering=True):
         raise NotImplementedError("DAGR detection forward is outside the EventAD hot path (EventAD only calls extract_features, models/EventAD.py:335-403)")
 
+    def train(self, mode=True):
+        self._in_eval = not mode                               # (set by nn.Module.train for the whole tree below)
+        return super().train(mode)
+
     def extract_features(self, x):
-        self.eval()
+        # evaluation mode on every call, as the reference (dagr.py:108-110) -- but the walk over the ~900 modules only when
+        # something switched modes since the last one
+        if self.training or not getattr(self, "_in_eval", False):
+            self.eval()
         with torch.no_grad():
             features = self.backbone(x)
             return features[0] if isinstance(features, (list, tuple)) else features

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...._lib import call, ptr
+from ...._lib import call, ptr, stream_handle
 
 BLOCKS = [3, 4, 6, 3]
 PLANES = [64, 128, 256, 512]
@@ -132,7 +132,7 @@ class NativeCNN:
         ws = self._ws
         call("eventad_conv2d_nhwc", ptr(x), ptr(w), ptr(out), ptr(bias), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
              ptr(residual), B, IH, IW, Cin, OH, OW, Cout, K, K, stride, pad, relu, ptr(ws), ws.numel() if ws is not None else 0,
-             torch.cuda.current_stream().cuda_stream)
+             stream_handle())
         return out, OH, OW
 
     def workspace_floats(self, B, H, W):
@@ -163,7 +163,7 @@ class NativeCNN:
 
     def _run(self, image, B, H, W):
         plan = image is None
-        st = None if plan else torch.cuda.current_stream().cuda_stream
+        st = None if plan else stream_handle()
         x0 = None
         if not plan:
             x0 = torch.empty((B, H, W, 4), device=self.dev)

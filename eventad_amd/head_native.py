@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from ._lib import call, ptr
+from ._lib import call, ptr, stream_handle
 
 NT = 32
 from .ddp import PARAMS, flat_layout      # used head parameters in flat-buffer order = the all-reduce bucket layout
@@ -81,8 +81,10 @@ class NativeHead:
 
     def bound(self):
         """True while the model's parameters still alias the flat buffer (a later .to()/.cuda() breaks it)."""
-        params = dict(self.model.named_parameters())
-        return all(params[n].data_ptr() == self.P[n].data_ptr() for n, _ in PARAMS)
+        # (the head's 20 parameters by name: a dict of ALL named parameters walks the frozen backbone's several hundred
+        # tensors too -- 0.75 ms per forward of an eager loop that takes 3.5)
+        get = self.model.get_parameter
+        return all(get(n).data_ptr() == self.P[n].data_ptr() for n, _ in PARAMS)
 
     # ---------------------------------------------------------------- workspace
     def _alloc(self, B):
@@ -143,7 +145,7 @@ class NativeHead:
                                      bias.data_ptr() if bias is not None else 0, lda, ldb, ldc, M, N, K, ta, tb, acc, relu,
                                      1 if (keep and K > 256) else (self.w["cnt"][i].data_ptr() if (K > 256 and _TILE_CNT) else 0)]
         call("eventad_gemm_group64" if wide else "eventad_gemm_group", len(probs), ctypes.cast(d, ctypes.c_void_p),
-             torch.cuda.current_stream().cuda_stream)
+             stream_handle())
 
     @staticmethod
     def _desc(fn, width, rows, *extra):
@@ -151,7 +153,7 @@ class NativeHead:
         for i, row in enumerate(rows):
             for j, v in enumerate(row):
                 d[width * i + j] = v if isinstance(v, int) else (v.data_ptr() if v is not None else 0)
-        call(fn, len(rows), ctypes.cast(d, ctypes.c_void_p), *extra, torch.cuda.current_stream().cuda_stream)
+        call(fn, len(rows), ctypes.cast(d, ctypes.c_void_p), *extra, stream_handle())
 
     def _att(self, fn, valid, *probs):
         """Grouped attentions: prob = dict(Hn, Sprev, w, alpha, Snext, dSnext, dHn_out, dHn, dSpass, dw, H)."""
@@ -161,7 +163,7 @@ class NativeHead:
     @staticmethod
     def _gemm(ta, tb, A, lda, Bm, ldb, C, ldc, M, N, K, bias=None, relu=0, acc=0):
         call("eventad_gemm_f32_ex", ta, tb, _rp(A), lda, _rp(Bm), ldb, _rp(C), ldc, M, N, K, _rp(bias), relu, acc,
-             torch.cuda.current_stream().cuda_stream)
+             stream_handle())
 
     # ------------------------------------------------------------------ forward
     def fill_masks(self, masks, step_dev=None):
@@ -175,7 +177,7 @@ class NativeHead:
         if step_dev is None:
             step, self.mask_step = self.mask_step, self.mask_step + 1
         call("eventad_dropout_masks", ptr(masks), masks.numel(), 0.7, self.mask_seed, step, ptr(step_dev),
-             torch.cuda.current_stream().cuda_stream)
+             stream_handle())
         return masks
 
     def next_mask_step(self, step_dev=None):
@@ -189,7 +191,7 @@ class NativeHead:
         Returns (loss 0-d, logits [B,32,2], valid bool[B,32], targets i64[B,32]); keeps what backward needs."""
         self._alloc(B)
         w, P = self.w, self.P
-        st = torch.cuda.current_stream().cuda_stream
+        st = stream_handle()
         R = B * NT
         M = int(bbox.shape[0]) if bbox is not None else 0
         bbox_c = bbox.contiguous().float() if M else None
@@ -267,7 +269,7 @@ class NativeHead:
         w, P = self.w, self.P
         ev, co = "gru_net_event.gru.", "gru_net_cor.gru."
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
-        st = torch.cuda.current_stream().cuda_stream
+        st = stream_handle()
         rows = lambda t, b: t[b * NT:(b + 1) * NT].data_ptr()
         for b in range(B + 1):
             d = (ctypes.c_int64 * 57)()
@@ -298,7 +300,7 @@ class NativeHead:
         """Fills `self.grads` (d loss / d every used parameter) for the last forward."""
         B, train = self._fw
         w, P, G = self.w, self.P, self.G
-        st = torch.cuda.current_stream().cuda_stream
+        st = stream_handle()
         R = B * NT
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
         # every used gradient entry is written (not accumulated) below; the attention vectors accumulate over the clips in
@@ -400,7 +402,7 @@ class NativeHead:
         w, P = self.w, self.P
         ev, co = "gru_net_event.gru.", "gru_net_cor.gru."
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
-        st = torch.cuda.current_stream().cuda_stream
+        st = stream_handle()
         rows = lambda t, b: t[b * NT:(b + 1) * NT].data_ptr()
         dS1, dS0, dSC = (w["dS1a"], w["dS1b"]), (w["dS0a"], w["dS0b"]), (w["dSCa"], w["dSCb"])
         pd = w["pd"]
@@ -434,7 +436,7 @@ class NativeHead:
         """clip_grad_norm_(grad_clip) + AdamW on the flat buffers; returns the (pre-clip) gradient norm."""
         call("eventad_clip_adamw", ptr(self.flat), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), float(self.clip),
-             ptr(self.partial), ptr(self.opt_state), torch.cuda.current_stream().cuda_stream)
+             ptr(self.partial), ptr(self.opt_state), stream_handle())
         return self.opt_state[1]
 
     def nonfinite_steps(self):

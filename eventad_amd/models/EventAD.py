@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .._lib import call, ptr
+from .._lib import call, ptr, stream_handle
 
 
 class _NativeHeadFn(torch.autograd.Function):
@@ -116,13 +116,23 @@ class EventADModel(nn.Module):
         self._calls = 0
         self.n_frames, self.fps, self.max_boxes = n_frames, fps, MAX_BOXES
         self.x_dim, self.h_dim = x_dim, h_dim
+        self._dagr_in_eval = False
+
+    def train(self, mode=True):
+        self._dagr_in_eval = False                             # (nn.Module.train walks into dagr_model as well)
+        return super().train(mode)
 
     # ------------------------------------------------------------------ features
     @torch.no_grad()
     def extract_features(self, data, frames=(0, 1)):
         """-> batch_features f32[B,2,31,64] (EventAD.py:335-403): backbone (HIP) + ROI pooling (HIP)."""
         self._calls += 1
-        self.dagr_model.eval()
+        # The reference puts the frozen backbone into evaluation mode on every call (EventAD.py:357-360); walking its ~900
+        # modules costs 1.5 ms of host time per forward, so it is done again only after something switched modes: train() /
+        # eval() of this model (below), or of the backbone itself.
+        if not self._dagr_in_eval or self.dagr_model.training:
+            self.dagr_model.eval()
+            self._dagr_in_eval = True
         out4 = self.dagr_model.extract_features(data)[1]
         return self.roi_features(out4, data, frames)
 
@@ -131,7 +141,7 @@ class EventADModel(nn.Module):
         """ROI pooling of the out4 node features per box (EventAD.py:382-397, 406-499) in csrc/roi.hip."""
         B = int(data.num_graphs)
         feats = torch.zeros((B, 2, T, self.x_dim), device=out4.x_padded.device)
-        st = torch.cuda.current_stream().cuda_stream
+        st = stream_handle()
         W, H = int(self.dagr_model.width), int(self.dagr_model.height)
         for frame, boxes, bb in ((1, getattr(data, "bbox", None), getattr(data, "bbox_batch", None)),
                                  (0, getattr(data, "bbox0", None), getattr(data, "bbox0_batch", None))):
@@ -227,8 +237,7 @@ class EventADModel(nn.Module):
         W, H = int(self.dagr_model.width), int(self.dagr_model.height)
         bbox, bb = getattr(data, "bbox", None), getattr(data, "bbox_batch", None)
         if torch.is_grad_enabled():
-            params = dict(self.named_parameters())
-            return _NativeHeadFn.apply(nh, feats, bbox, bb, labels, B, W, H, self.training, *[params[n] for n, _ in PARAMS])
+            return _NativeHeadFn.apply(nh, feats, bbox, bb, labels, B, W, H, self.training, *[self.get_parameter(n) for n, _ in PARAMS])
         if lean:                                               # TrainStep: results stay in the head's static buffers
             return nh.forward(feats, bbox, bb, labels, B, W, H, self.training, lean=True, masks=masks)
         loss, logits, valid, targets = nh.forward(feats, bbox, bb, labels, B, W, H, self.training)
