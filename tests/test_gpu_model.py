@@ -360,3 +360,29 @@ def test_two_graph_pipeline_restarts_after_a_flush_and_closes_its_streams():
     assert out[0][1] == out[1][1] == 4.0
     for k in out[0][0]:
         assert torch.equal(out[0][0][k], out[1][0][k]), k
+
+
+def test_captured_evaluation_forward_equals_the_eager_one():
+    """InferStep: the evaluation forward as one replayed hipGraph, with the live trunk, fed three different batches of one
+    shape -- logits, validity and targets bitwise equal to the eager predict_tensors of the same batches."""
+    from eventad_amd.infer_step import InferStep
+    from eventad_amd.dagr.utils.buffers import format_data
+    W = H = 64
+    B, n = 3, 4000
+    from eventad_amd import synthetic
+    args, model, sd, head_sd, raw, data = _build(W, H, B, n, live_cnn=True)
+    model.eval()
+    batches = [format_data(synthetic.make_batch(W, H, n, B, first_clip=10 * i, with_image=True).to("cuda")) for i in range(4)]
+    with torch.no_grad():
+        eager = [[t.clone() for t in model.predict_tensors(d, d.bbox[:, 4])] for d in batches]
+    st = InferStep(model)
+    st.capture(batches[0])
+    for i in (1, 2, 3, 0, 2):
+        out = st.replay(batches[i])
+        torch.cuda.synchronize()
+        for a, b in zip(out, eager[i]):
+            assert torch.equal(a, b), i
+    model.train()
+    with pytest.raises(RuntimeError):
+        st.replay()
+
