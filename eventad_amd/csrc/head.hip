@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict_
 //   counted in [5] for the host's lazy check.
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
                                                float lr, float beta1, float omb1, float beta2, float omb2, float eps, float decay,
-                                               float max_norm, const float* __restrict__ partial, float* __restrict__ state) {
+                                               float max_norm, const float* __restrict__ partial, float* __restrict__ state,
+                                               const float* __restrict__ loss_in, float* __restrict__ result_out) {
     __shared__ float s_norm;
     // A thread's elements (two groups of four consecutive ones, a grid apart: 16-byte loads and stores; the update is pure
     // streaming, 7 floats of traffic per parameter, and runs on the head's CU share) are requested BEFORE the norm is formed
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __r
         if (!finite) state[5] += 1.f;
         state[6] = skip ? 1.f : 0.f; state[2] = skip ? 1.f : coef;
         if (!skip) state[0] = state[7];
+        if (result_out) { result_out[0] = loss_in ? loss_in[0] : 0.f; result_out[1] = norm; }
     }
     if (skip) return;
     const float bc1 = state[3], bc2s = sqrtf(state[4]);
@@ -512,17 +514,26 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __r
     }
 }
 
-extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr,
-                                  double beta1, double beta2, double eps, double weight_decay, double max_norm,
-                                  float* partial, float* state, void* stream) {
+/* eventad_clip_adamw that also leaves the step's (loss, gradient norm) in result_out f32[2] (loss read from loss_in f32[1];
+ * written by the update's own launch: a caller that keeps several steps' results needs no copy launch behind it). */
+extern "C" int eventad_clip_adamw_out(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr,
+                                      double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                                      float* partial, float* state, const float* loss_in, float* result_out, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !partial || !state || n <= 0) return EVAD_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return EVAD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sqnorm_partial, dim3(NORM_BLOCKS), dim3(256), 0, st, grads, n, partial, beta1, beta2, state);
     hipLaunchKernelGGL(k_adamw, dim3(evad_blocks(((long long)n + 7) / 8, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, (float)lr,
                        (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)(1.0 - lr * weight_decay), (float)max_norm, partial, state);
+                       (float)(1.0 - lr * weight_decay), (float)max_norm, partial, state, loss_in, result_out);
     return evad_last_error();
+}
+
+extern "C" int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr,
+                                  double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                                  float* partial, float* state, void* stream) {
+    return eventad_clip_adamw_out(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, max_norm, partial,
+                                  state, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -76,6 +76,8 @@ class NativeHead:
         self.mask_step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         # launch form of the clip recurrence: one fused launch per stage (default) or the older two / three launches per stage
         self.stage_fwd, self.stage_bwd = _STAGE_FWD, _STAGE_BWD
+        self.result_out = None                                # f32[2] that optimizer_step also writes (loss, norm) to
+        self.tables = None                                    # input tables filled ahead of forward() (fill_tables)
         self.keep_superseded_workspaces = False               # set once a hipGraph holds pointers into the workspace
         self._retired_ws = []
 
@@ -185,14 +187,19 @@ class NativeHead:
         (self.mask_step_dev if step_dev is None else step_dev).fill_(self.mask_step)
         self.mask_step += 1
 
-    def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train, lean=False, masks=None):
-        """feats f32[B,2,31,64] (ROI features), bbox f32[M,6], bbox_batch i64[M], labels f32[M] or None.
-        masks: this step's dropout masks, already drawn by fill_masks (default: drawn here, when train).
-        Returns (loss 0-d, logits [B,32,2], valid bool[B,32], targets i64[B,32]); keeps what backward needs."""
+    def new_tables(self, B):
+        """A set of the head's input tables (track features, box coordinates, targets, validity) for fill_tables."""
+        R, dev = B * NT, self.dev
+        return {"X": torch.zeros((R, 64), device=dev), "CO": torch.zeros((R, 4), device=dev),
+                "target": torch.zeros(R, dtype=torch.int32, device=dev), "valid": torch.zeros(R, dtype=torch.int32, device=dev)}
+
+    def fill_tables(self, tables, feats, bbox, bbox_batch, labels, B, width, height):
+        """The first launch of forward() on its own, into `tables`: it depends on the batch and its ROI features only, not on
+        the weights, so a pipelined caller issues it behind the backbone and hands the set to forward() through self.tables."""
         self._alloc(B)
-        w, P = self.w, self.P
-        st = stream_handle()
-        R = B * NT
+        self._launch_tables(feats, bbox, bbox_batch, labels, B, width, height, tables)
+
+    def _launch_tables(self, feats, bbox, bbox_batch, labels, B, width, height, dst):
         M = int(bbox.shape[0]) if bbox is not None else 0
         bbox_c = bbox.contiguous().float() if M else None
         bb_c = bbox_batch.contiguous().long() if M else None
@@ -204,7 +211,25 @@ class NativeHead:
             else:
                 lab_c = labels.contiguous().float()
         call("eventad_head_tables", _rp(bbox_c), _rp(bb_c), M, _rp(lab_c), label_col, ptr(feats), B, int(width), int(height),
-             ptr(w["X"]), ptr(w["CO"]), ptr(w["target"]), ptr(w["valid"]), st)
+             ptr(dst["X"]), ptr(dst["CO"]), ptr(dst["target"]), ptr(dst["valid"]), stream_handle())
+
+    def forward(self, feats, bbox, bbox_batch, labels, B, width, height, train, lean=False, masks=None):
+        """feats f32[B,2,31,64] (ROI features), bbox f32[M,6], bbox_batch i64[M], labels f32[M] or None.
+        masks: this step's dropout masks, already drawn by fill_masks (default: drawn here, when train).
+        Returns (loss 0-d, logits [B,32,2], valid bool[B,32], targets i64[B,32]); keeps what backward needs."""
+        self._alloc(B)
+        P = self.P
+        st = stream_handle()
+        R = B * NT
+        if self.tables is None:
+            self._launch_tables(feats, bbox, bbox_batch, labels, B, width, height, self.w)
+            w = self.w
+        else:
+            # the tables of this batch were filled ahead of time (fill_tables, e.g. at the end of the backbone's graph): the
+            # head's launches below read them in place of the workspace's own
+            w = dict(self.w)
+            w.update(self.tables)
+        self._w_fw = w
         self.D1 = self.D2 = None
         if train:                                              # nn.GRU(dropout=.3) between layers; fusion Dropout(.3):
             D = masks if masks is not None else self.fill_masks(w["D"])      # both masks in two launches
@@ -266,7 +291,7 @@ class NativeHead:
         coordinate GRU on clip b and GRU layer 1 on clip b-1; the attention that turns a clip's cell outputs into the next
         clip's state is computed at the start of the stage that consumes it.  Fills the same buffers as the two-launch form
         (the state after the LAST clip and its attention weights, which nothing reads, are not computed)."""
-        w, P = self.w, self.P
+        w, P = self._w_fw, self.P                              # (the forward's view of the workspace: its input tables may be a set of their own)
         ev, co = "gru_net_event.gru.", "gru_net_cor.gru."
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
         st = stream_handle()
@@ -299,7 +324,7 @@ class NativeHead:
     def backward(self):
         """Fills `self.grads` (d loss / d every used parameter) for the last forward."""
         B, train = self._fw
-        w, P, G = self.w, self.P, self.G
+        w, P, G = self._w_fw, self.P, self.G
         st = stream_handle()
         R = B * NT
         ev, co, fu = "gru_net_event.gru.", "gru_net_cor.gru.", "fusion_module."
@@ -399,7 +424,7 @@ class NativeHead:
         coordinate GRU on clip b and GRU layer 0 on clip b+1.  A stage first forms, for its columns, the products that
         carry the previous stage's gate gradients to this clip's state (and, for layer 0, to its dropout'd output), then
         does attention + cell backward; the attention's row dots come from partial dots the previous stage left."""
-        w, P = self.w, self.P
+        w, P = self._w_fw, self.P                              # (the forward's view of the workspace: its input tables may be a set of their own)
         ev, co = "gru_net_event.gru.", "gru_net_cor.gru."
         watt, wattc = P["soft_attention.weight"], P["soft_attention_cor.weight"]
         st = stream_handle()
@@ -434,9 +459,12 @@ class NativeHead:
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self):
         """clip_grad_norm_(grad_clip) + AdamW on the flat buffers; returns the (pre-clip) gradient norm."""
-        call("eventad_clip_adamw", ptr(self.flat), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
+        # result_out (set by a caller that keeps several steps' results, TrainStep.capture_dual): the update's own launch
+        # leaves (loss, norm) there
+        res = self.result_out
+        call("eventad_clip_adamw_out", ptr(self.flat), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), float(self.clip),
-             ptr(self.partial), ptr(self.opt_state), stream_handle())
+             ptr(self.partial), ptr(self.opt_state), ptr(self.w["loss"]) if res is not None else None, ptr(res), stream_handle())
         return self.opt_state[1]
 
     def nonfinite_steps(self):

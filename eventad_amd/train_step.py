@@ -279,18 +279,29 @@ class TrainStep:
                     step_dev = torch.zeros(1, dtype=torch.int64, device=masks.device)   # set before each replay (_issue_backbone)
                 d["mask_step"].append(step_dev)
                 d["masks"].append(masks)                       # the graphs hold raw pointers: the buffer must outlive this call
+                # so do the head's input tables (track features, box coordinates, targets, validity: a function of the batch
+                # and its ROI features, not of the weights): filled behind the backbone into a set of the chain's own, which
+                # the head graph then reads in place of the shared workspace's
+                hi = in_h[c]
+                tabs = self.nh.new_tables(hi.num_graphs)
+                W_, H_ = int(self.model.dagr_model.width), int(self.model.dagr_model.height)
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     feats = self.model.extract_features(in_b[c], frames=(1,))
+                    self.nh.fill_tables(tabs, feats, hi.bbox, hi.bbox_batch, hi.bbox[:, 4], hi.num_graphs, W_, H_)
                     if masks is not None:
                         self.nh.fill_masks(masks, step_dev)
-                # the head's loss and gradient norm live in the ONE head workspace every chain shares: each head graph ends
-                # by copying them into two floats of its own, so a step's results stay readable until the chain's next turn
-                res = torch.zeros(2, device=in_h[c].bbox.device)
-                with torch.cuda.graph(gh, capture_error_mode="thread_local"):
-                    loss, norm = self._head_update(feats, in_h[c], masks=masks)
-                    self._copy_pairs([(res[0:1], loss.reshape(1)), (res[1:2], norm.reshape(1))])
+                # the head's loss and gradient norm live in the ONE head workspace every chain shares: the update's own launch
+                # also leaves them in two floats of the chain's, so a step's results stay readable until the chain's next turn
+                res = torch.zeros(2, device=hi.bbox.device)
+                self.nh.tables, self.nh.result_out = tabs, res
+                try:
+                    with torch.cuda.graph(gh, capture_error_mode="thread_local"):
+                        self._head_update(feats, hi, masks=masks)
+                finally:
+                    self.nh.tables, self.nh.result_out = None, None
                 out = (res[0], res[1])
                 d.setdefault("res", []).append(res)
+                d.setdefault("tabs", []).append(tabs)        # (the graphs hold raw pointers)
                 if native is not None:
                     native.select_workspace(0)
             d["gb"].append(gb); d["gh"].append(gh); d["feats"].append(feats); d["out"].append(out)

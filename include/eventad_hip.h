@@ -337,6 +337,12 @@ int eventad_colsum_group(int n, const int64_t* desc, int R, void* stream);
 int eventad_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr, double beta1,
                        double beta2, double eps, double weight_decay, double max_norm, float* partial, float* state,
                        void* stream);
+/* The same update, which also leaves the step's (loss, gradient norm) in result_out f32[2] -- loss read from loss_in f32[1] --
+ * from the update's own launch: what utils/train.py:123-152 reads back with .item() after the step, kept per step without a
+ * copy launch behind the update (NULL result_out = eventad_clip_adamw). */
+int eventad_clip_adamw_out(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n, double lr, double beta1,
+                           double beta2, double eps, double weight_decay, double max_norm, float* partial, float* state,
+                           const float* loss_in, float* result_out, void* stream);
 
 /* Dropout masks of one training step: out f32[n] (16-byte aligned) = 1/keep_prob with probability keep_prob, else 0
  * (the inter-layer dropout of nn.GRU and nn.Dropout of the fusion MLP, models/EventAD.py:26,86; the reference draws them
