@@ -441,6 +441,21 @@ extern "C" int eventad_copy_group(int n, const void* const* src, void* const* ds
     return evad_last_error();
 }
 
+// The same hand-over for a batch that sits in PINNED host memory: n asynchronous host-to-device copies on the given stream.
+// (Plain hipMemcpyAsync; what it is for is the stream it is given: the CU-masked streams of a pipelined step are created
+// outside torch, and a torch copy from pinned memory makes torch's host allocator record events on the copying stream that
+// it touches again when the buffer is freed -- possibly after that stream is gone.)  The caller keeps the host buffers alive
+// and unchanged until the stream has passed the copies.
+extern "C" int eventad_copy_to_device(int n, const void* const* src_host, void* const* dst, const uint64_t* bytes, void* stream) {
+    if (n < 0 || (n > 0 && (!src_host || !dst || !bytes))) return EVAD_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] == 0) continue;
+        if (!src_host[i] || !dst[i]) return EVAD_ERR_ARG;
+        if (hipMemcpyAsync(dst[i], src_host[i], bytes[i], hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return evad_last_error() ? evad_last_error() : -2;
+    }
+    return EVAD_OK;
+}
+
 // =============================================================================================
 // (B) native path: counting sort by pixel + ELL edge search
 // =============================================================================================

@@ -65,6 +65,10 @@ int eventad_format_events(const int16_t* pos, const int32_t* t, const int8_t* x,
  * copies src[i] -> dst[i] of bytes[i] bytes in ONE launch.  src / dst / bytes are HOST arrays (read before the call
  * returns); segments must not overlap each other's destinations. */
 int eventad_copy_group(int n, const void* const* src, void* const* dst, const uint64_t* bytes, void* stream);
+/* The same hand-over for a batch in PINNED host memory (a loader's collated batch, utils/train.py:120-122 does `data.to(device)`):
+ * n asynchronous host-to-device copies on `stream`.  The host buffers stay alive and unchanged until the stream has passed
+ * the copies. */
+int eventad_copy_to_device(int n, const void* const* src_host, void* const* dst, const uint64_t* bytes, void* stream);
 
 /* ---- (B) native graph build: replaces EV_TGN.forward + SlidingWindowGraph.forward ------------- */
 /* (ev_tgn.py:39-58, ev_graph.py:62-103, graph/utils.py:6-23) for one fresh batch.

@@ -147,6 +147,18 @@ def test_live_cnn_configurations_match_oracle(W, H, B, n):
     assert float((got - want).abs().max()) < 1e-3 and torch.equal(got.argmax(1), want.argmax(1))
 
 
+def _pinned(d):
+    """The batch with every tensor the step loads in pinned host memory."""
+    h = d.clone()
+    for k in ("pos", "x", "batch", "bbox", "bbox_batch", "bbox0", "bbox0_batch", "image"):
+        v = getattr(d, k, None)
+        if isinstance(v, torch.Tensor):
+            setattr(h, k, v.cpu().pin_memory())
+    if getattr(d, "image_feats", None) is not None:
+        h.image_feats = [m.cpu().pin_memory() for m in d.image_feats]
+    return h
+
+
 def _run_mode(mode, ts, batches):
     """Run one optimisation step per batch in the given launch form; -> per-step losses the form can report (floats are
     read after a synchronisation: for the no-join forms only each chain's last result is still there)."""
@@ -177,15 +189,24 @@ def _run_mode(mode, ts, batches):
         assert ts._dual["masked"] == ("unmasked" not in mode) or "masked" not in mode
         assert n == (int(mode.split("chains")[0][-1]) if "chains" in mode else (3 if ts._dual["masked"] else 2))
         held = []
-        for i, b in enumerate(batches[1:]):
-            r = ts.replay_dual(b, join=join)
-            assert (r is None) == (i < prefetch - 1)     # the first prefetch - 1 calls only start backbone passes
-            if r is None:
-                continue
-            held.append(r[0])
-            if join:
-                losses.append(r[0].clone())
-        held.append(ts.flush()[0])                       # (runs the head updates of all batches still in the pipeline)
+        import contextlib
+        feed = batches[1:]
+        if "hostbatches" in mode:                        # batches handed over in pinned host memory
+            feed = [_pinned(b) for b in feed]
+        # a loop that hands over batches runs under a stream of its own (work on the legacy default stream is a barrier
+        # across the pipeline's CU-masked streams)
+        own = "hostbatches" in mode or "callerstream" in mode
+        torch.cuda.synchronize()
+        with (torch.cuda.stream(ts.caller_stream()) if own else contextlib.nullcontext()):
+            for i, b in enumerate(feed):
+                r = ts.replay_dual(b, join=join)
+                assert (r is None) == (i < prefetch - 1)     # the first prefetch - 1 calls only start backbone passes
+                if r is None:
+                    continue
+                held.append(r[0])
+                if join:
+                    losses.append(r[0].clone())
+            held.append(ts.flush()[0])                       # (runs the head updates of all batches still in the pipeline)
         torch.cuda.synchronize()
         if prefetch > 1:
             losses = [held[-1].clone()]                  # flush() reports the last of its head updates only
@@ -220,7 +241,7 @@ def test_pipelined_and_graph_steps_equal_sequential_steps():
     results = []
     for mode in ("sequential", "pipelined", "graph", "dual", "dual_nojoin", "dual_masked", "dual_unmasked_nojoin",
                  "dual_masked_nojoin_3chains", "dual_masked_nojoin_4chains", "dual_2chains", "dual_masked_nojoin_3chains_prefetch2",
-                 "dual_masked_4chains_prefetch3"):
+                 "dual_masked_4chains_prefetch3", "dual_masked_nojoin_3chains_callerstream", "dual_masked_nojoin_3chains_hostbatches"):
         args, model, sd, head_sd, raw, data = _build(W, H, B, n)
         from dagr.utils.buffers import format_data
         batches = [data] + [format_data(synthetic.make_batch(W, H, n, B, first_clip=3 * k, with_image=False,
