@@ -35,6 +35,12 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.eventad_dropout_masks(None, 16, 0.7, 1, 0, None, None) == -1
     assert lib.eventad_conv2d_workspace_floats(1, 8, 8, 16, 16, 3, 3, None) == -1
     assert lib.eventad_clip_adamw(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None, None, None) == -1
+    assert lib.eventad_clip_adamw_out(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None, None, None, None, None) == -1
+    assert lib.eventad_gemm_group64(0, None, None) == -1 and lib.eventad_gemm_group64(9, None, None) == -1
+    import ctypes
+    desc = (ctypes.c_int64 * 16)()                           # one problem with null operands
+    assert lib.eventad_gemm_group64(1, desc, None) == -1
+    assert lib.eventad_copy_to_device(1, None, None, None, None) == -1 and lib.eventad_copy_to_device(0, None, None, None, None) == 0
 
 
 def test_spiral_table_matches_oracle():
