@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the frozen backbone of batch k+1 with the head update of batch k")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct device-resident batches handed to the step in rotation, a different one every step "
+                         "(1 = every step re-runs the batch the step object already holds: no batch-load launch in the step)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,12 +153,20 @@ def main():
     W, H, n_ev, B, live = synthetic.CONFIGS[a.config]
     args, model, sd = build_model(W, H, B, dev, live_cnn=live)
     from dagr.utils.buffers import format_data
-    raw = synthetic.make_config_batch(a.config, first_clip=rank * B)        # each rank owns different clips
-    data = format_data(raw.clone().to(dev))
-    if getattr(data, "image_feats", None) is not None:
-        # precomputed CNN feature maps are kept in channels-last memory format ([B,C,h,w] tensors, NHWC in memory): the
-        # layout every sampler kernel reads, so the step has no layout-change launch (plain NCHW maps are accepted too)
-        data.image_feats = [m.contiguous(memory_format=torch.channels_last) for m in data.image_feats]
+    R = max(1, a.rotate)
+
+    def resident(i, keep_raw=False):
+        r = synthetic.make_config_batch(a.config, first_clip=(rank * R + i) * B)        # each rank owns different clips
+        d = format_data(r.clone().to(dev))
+        if getattr(d, "image_feats", None) is not None:
+            # precomputed CNN feature maps are kept in channels-last memory format ([B,C,h,w] tensors, NHWC in memory): the
+            # layout every sampler kernel reads, so the step has no layout-change launch (plain NCHW maps are accepted too)
+            d.image_feats = [m.contiguous(memory_format=torch.channels_last) for m in d.image_feats]
+        return (r, d) if keep_raw else d
+
+    raw, data = resident(0, keep_raw=True)
+    # the batches of the timed region: R distinct ones, all resident in HBM before the timer starts, a different one every step
+    pool = [data] + [resident(i) for i in range(1, R)]
     model.train()                                                           # as utils/train.py:90 (dropout active)
     ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
     nb = model.dagr_model.backbone._native
@@ -174,13 +185,18 @@ def main():
             if pipelined:
                 # backbone graphs || head graph on event-coupled streams; the backbone runs as far ahead of the head as the
                 # chains allow, so the timed region starts with that many finished passes in hand (as it ends with them)
-                ts.capture_dual(data, prefetch="max")
+                ts.capture_dual(data.clone(), prefetch="max")
                 while ts._dual["issued"] - ts._dual["k"] < ts._dual["prefetch"]:
                     ts.replay_dual(join=False)                 # fill: these calls only start backbone passes
-                run = lambda: ts.replay_dual(join=False)       # the timed region ends with a device-wide sync
+                # (the timed region ends with a device-wide sync)
+                run = (lambda k: ts.replay_dual(join=False)) if R == 1 else (lambda k: ts.replay_dual(pool[k % R], join=False))
             else:
-                ts.capture(data)
-                run = ts.replay
+                held = data.clone()
+                ts.capture(held)
+                def run(k):
+                    if R > 1:
+                        TrainStep.load_into(held, pool[k % R])
+                    return ts.replay()
         except Exception as e:
             if world > 1:
                 # the multi-GPU number is defined on the captured pipeline (all-reduce inside the head graph): an eager run
@@ -191,21 +207,40 @@ def main():
             torch.cuda.synchronize()
             use_graph = pipelined = False
     if not use_graph:
-        run = lambda: ts.step(data)
+        run = lambda k: ts.step(pool[k % R])
         if not a.no_kernel_timing:
             nb.timing = {}
     # untimed: the replayed graphs' first runs (cold caches, pipeline fill), and enough of them that the timed region does not
     # start on a chip that idled through the capture (the clocks take some milliseconds of load to come up: without this a
     # 20-step region reads 3-4 % slower than a 300-step one)
     n_warm = int(os.environ.get("EVENTAD_BENCH_GRAPH_WARMUP", "40"))
-    for _ in range(n_warm if use_graph else 0):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, norm = run()
-    barrier()
-    dt = time.perf_counter() - t0
+    # The loop that hands batches to the pipelined step runs under a stream of its own: the pipeline's CU-masked streams are
+    # blocking streams, and anything on the legacy default stream -- the event that makes a chain wait for the stream its next
+    # batch was produced on included -- would be a barrier across all of them.
+    import contextlib
+    loop_stream = (lambda: torch.cuda.stream(ts.caller_stream())) if (pipelined and R > 1) else contextlib.nullcontext
+
+    def timed(fn, steps):
+        with loop_stream():
+            barrier()
+            t_ = time.perf_counter()
+            out_ = None
+            for k in range(steps):
+                out_ = fn(k)
+            barrier()
+            return time.perf_counter() - t_, out_
+
+    with loop_stream():
+        for k in range(n_warm if use_graph else 0):
+            run(k)
+    dt, (loss, norm) = timed(run, a.steps)
+    held_rate = None
+    if pipelined and R > 1 and world == 1:
+        # beside it: the same steps on the batch each chain holds (no batch-load launch in the step)
+        for k in range(10):
+            ts.replay_dual(join=False)
+        dt_h, _ = timed(lambda k: ts.replay_dual(join=False), a.steps)
+        held_rate = round(B * a.steps / dt_h, 1)
     if use_graph and not a.no_kernel_timing:
         # per-kernel HIP-event timing of the same K steps, launched eagerly on the same stream (a graph
         # replay cannot be bracketed per kernel); the launch durations are those of the timed region.
@@ -235,7 +270,10 @@ def main():
                        "untimed_graph_replays": n_warm if use_graph else 0,
                        "pipeline": ("none" if not pipelined else "backbone(k+1..k+%d) || head update(k): hipGraphs on event-coupled streams, %d backbone chains (own workspace set and stream each), backbone %d batch(es) ahead, head updates in order on one stream" % (ts._dual["n"] - 1, ts._dual["n"], ts._dual["prefetch"])),
                          "cu_partition": ("head graph on %d CUs of its own, backbone graph on the others (CU-masked default-priority streams)" % ((ts.head_cus if ts.head_cus > 0 else torch.cuda.get_device_properties(0).multi_processor_count // 8)) if (pipelined and ts._dual and ts._dual.get("masked")) else "none"),
-                       "input": "device-resident batch, H2D copy excluded; every step runs the full backbone + head update on it; precomputed feature maps stored channels-last (NHWC in memory)",
+                       "input": ("%d distinct device-resident batches in rotation, a different one every step (its one-launch load into the step's static buffers is inside the timed region); H2D copy excluded" % R if R > 1
+                                 else "device-resident batch, H2D copy excluded; every step re-runs the full backbone + head update on the batch the step holds")
+                                + "; precomputed feature maps stored channels-last (NHWC in memory)",
+                       "clips_per_s_on_the_held_batch": held_rate,
                        "skipped_vs_reference": "ROI pooling of the previous-frame boxes (computed by the reference, never read by its forward)",
                        "grad_allreduce_bytes": ts.bucket_bytes if world > 1 else 0,
                        "final_loss": round(float(loss), 4)},

@@ -1,7 +1,7 @@
 """The pipelined C2 step fed a DIFFERENT batch every step: (a) batches resident on the device (the one-launch load into the
 chain's static buffers is then inside the step), (b) formatted batches in pinned host memory (the host-to-device copies run on the
 chain's backbone stream, in front of its graph).  bench.py's `value` replays the batch each chain holds; these are the rates a
-training loop sees.  usage: python tools/exp_host_batches.py [steps=300]"""
+training loop sees.  usage: python tools/exp_host_batches.py [steps=300] [distinct_batches=6]"""
 import os, sys, time, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -17,7 +17,7 @@ def make(i):
     d = format_data(synthetic.make_config_batch("C2", first_clip=i * B).to(dev))
     d.image_feats = [m.contiguous(memory_format=torch.channels_last) for m in d.image_feats]
     return d
-pool = [make(i) for i in range(6)]
+pool = [make(i) for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6)]
 ts = TrainStep(model, lr=args.learning_rate, weight_decay=1e-5, grad_clip=args.grad_clip)
 ts.capture_dual(pool[0].clone(), prefetch="max")
 def pinned(d):
