@@ -425,6 +425,16 @@ class TrainStep:
             pairs.extend(zip(in_b.image_feats, batch.image_feats))
         return pairs
 
+    @staticmethod
+    def _any_on_device(batch):
+        """Does any tensor that a step loads from this batch live on the GPU (i.e. may still be in the making on the
+        caller's stream)?"""
+        for k in ("pos", "x", "batch", "image", "bbox", "bbox_batch", "bbox0", "bbox0_batch"):
+            v = getattr(batch, k, None)
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                return True
+        return any(m.is_cuda for m in (getattr(batch, "image_feats", None) or ()))
+
     @classmethod
     def load_into(cls, in_b, batch):
         """Copy a batch into static (captured) input buffers of the same shapes, on the current stream."""
@@ -471,7 +481,7 @@ class TrainStep:
         # hipExtStreamCreateWithCUMask takes no flags -- so ANY operation on the legacy default stream, the event of this wait
         # included, is a barrier across all of them and serialises the pipeline (C2: 1.35 instead of 0.58 ms per step): run the
         # loop under a stream of its own (`with torch.cuda.stream(ts.caller_stream()):`).
-        wait_main = join or (next_batch is not None and next_batch.pos.is_cuda)
+        wait_main = join or (next_batch is not None and self._any_on_device(next_batch))
         if d["drained"] or d["issued"] - d["k"] < d["prefetch"]:
             # after flush(), or while the backbone is not yet `prefetch` batches ahead: only start this batch's backbone pass
             d["drained"] = False
